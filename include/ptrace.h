@@ -1,0 +1,181 @@
+/*
+ * ptrace.h - C ABI of libptrace: the path-tracing compute kernel of
+ * VirtualEngineeringLab/Pathtracing (Assets/Scripts/RayTracingShader.compute,
+ * kernel CSMain, plain path-trace mode) plus progressive accumulation
+ * (Assets/Shaders/AddMat.shader), implemented as HIP kernels for gfx950.
+ *
+ * Each entry point replaces one call the reference's C# host
+ * (Assets/Scripts/RayTracingMaster.cs) makes on UnityEngine.ComputeShader /
+ * ComputeBuffer / RenderTexture; the replaced call is cited beside it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a PT_ERR_* code otherwise, and never
+ *     throws; pt_last_error() gives the text of the last failure of a context
+ *     (or of pt_create when passed NULL);
+ *   - `const` host pointers are copied during the call (ComputeBuffer.SetData
+ *     semantics); the caller may free them on return;
+ *   - a context belongs to one device and is not thread-safe (Unity drives its
+ *     ComputeShader from the main thread only); different contexts may be used
+ *     from different threads;
+ *   - pt_render() enqueues on the context's HIP stream and returns; pt_sync()
+ *     and the pt_read_* calls wait for it;
+ *   - matrices are 16 floats in UnityEngine.Matrix4x4 memory order
+ *     (column-major: element (row i, col j) at [j*4+i]);
+ *   - images are RGBA float32, row-major, pixel (x,y) at [(y*W + x)*4], y as
+ *     SV_DispatchThreadID.y (RayTracingShader.compute:726).
+ */
+#ifndef PTRACE_H
+#define PTRACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_ERR_INVALID 1   /* bad argument / bad state           */
+#define PT_ERR_HIP 2       /* a HIP runtime call failed          */
+#define PT_ERR_NOMEM 3     /* host or device allocation failed   */
+#define PT_ERR_UNSUPPORTED 4
+
+typedef struct pt_context pt_context;
+
+/* struct Sphere, RayTracingMaster.cs:100-108 / RayTracingShader.compute:61-69; stride 56 (RayTracingMaster.cs:366). */
+typedef struct PtSphere {
+    float position[3];
+    float radius;
+    float albedo[3];
+    float specular[3];
+    float smoothness;
+    float emission[3];
+} PtSphere;
+
+/* struct MeshObject, RayTracingMaster.cs:93-98 / RayTracingShader.compute:77-82; stride 72 (RayTracingMaster.cs:410). */
+typedef struct PtMeshObject {
+    float local_to_world[16];
+    int32_t indices_offset;
+    int32_t indices_count;
+} PtMeshObject;
+
+/* Accumulation of the fresh frame into the converged image. */
+enum {
+    PT_ACCUM_NONE = 0,   /* Result only                                                            */
+    PT_ACCUM_MEAN = 1,   /* converged = converged*(1 - 1/(S+1)) + fresh/(S+1), all four channels   */
+    PT_ACCUM_SUM = 2,    /* converged += fresh (S == 0: converged = fresh); for sample sharding     */
+    PT_ACCUM_ADDMAT = 3  /* AddMat.shader:44-63 with its SrcAlpha/OneMinusSrcAlpha blend (:11)      */
+};
+
+/* Which render target a device pointer is bound to (pt_bind_target). */
+enum {
+    PT_TARGET_RESULT = 0,     /* "Result"  (RayTracingMaster.cs:740)  RGBA32F W*H */
+    PT_TARGET_CONVERGED = 1,  /* "Result1" (RayTracingMaster.cs:741)  RGBA32F W*H */
+    PT_TARGET_HIT_IDS = 2     /* int32 W*H primary-hit ids; no counterpart in the reference (parity aid) */
+};
+
+/* Per-dispatch uniforms: what SetShaderParameters() (RayTracingMaster.cs:455-540)
+ * and Render() (:735-738) upload before Dispatch. */
+typedef struct PtFrameParams {
+    float camera_to_world[16];           /* _CameraToWorld            RayTracingMaster.cs:464,489 */
+    float camera_inverse_projection[16]; /* _CameraInverseProjection  RayTracingMaster.cs:467,490 */
+    float seed;                          /* _Seed                     RayTracingMaster.cs:530     */
+    int32_t samples_per_pixel;           /* _SamplesPerPixel          RayTracingMaster.cs:531     */
+    int32_t max_bounces;                 /* path segments per sample; the shader hard-codes 4
+                                            (RayTracingShader.compute:866-873); must be >= 1     */
+    int32_t depth;                       /* _Depth                    RayTracingMaster.cs:532     */
+    int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735); only 1 = Default */
+    uint32_t sample_index;               /* _Sample of AddMat.shader:42 (RayTracingMaster.cs:805) */
+    int32_t accumulate;                  /* PT_ACCUM_*                                            */
+    int32_t tile_x0, tile_y0;            /* sub-rectangle of the image this dispatch renders;     */
+    int32_t tile_w, tile_h;              /*   tile_w == 0 or tile_h == 0 means the whole image    */
+    float pixel_offset[2];               /* _PixelOffset      uploaded, unused (RayTracingShader.compute:21,842) */
+    float directional_light[4];          /* _DirectionalLight uploaded, unused (RayTracingShader.compute:19)    */
+} PtFrameParams;
+
+/* Counters over every pt_render() issued since the previous pt_get_stats()
+ * (or since pt_create); pt_get_stats() waits for those renders. */
+typedef struct PtStats {
+    uint64_t rays;            /* Trace() calls executed by the kernels                      */
+    uint64_t nodes_visited;   /* BVH nodes fetched                                          */
+    uint64_t prims_tested;    /* triangle + sphere intersection tests                       */
+    uint64_t paths;           /* camera rays generated (pixels * samples)                   */
+    float kernel_ms;          /* device time from the first of those renders' start to the
+                                 last one's end (HIP events on the context's stream)        */
+    int32_t bvh_nodes;        /* scene statistics                                           */
+    int32_t bvh_prims;
+    int32_t bvh_depth;
+    float bvh_build_ms;       /* host time of the last BVH build                            */
+} PtStats;
+
+/* Create / destroy a context on HIP device `device_ordinal` (replaces the
+ * ComputeShader instance + its GPU resources; released like
+ * RayTracingMaster.cs:154-161). */
+int pt_create(int device_ordinal, pt_context **out_ctx);
+void pt_destroy(pt_context *ctx);
+const char *pt_last_error(const pt_context *ctx);
+
+/* Run on an existing hipStream_t (e.g. the caller's current stream) instead of
+ * the context's own; NULL restores the context's stream. */
+int pt_set_stream(pt_context *ctx, void *hip_stream);
+
+/* _Spheres: new ComputeBuffer(count,56).SetData + SetBuffer (RayTracingMaster.cs:366-367,536).
+ * count == 0 is valid (buffer not bound, RayTracingMaster.cs:445). */
+int pt_set_spheres(pt_context *ctx, const PtSphere *spheres, int count);
+
+/* _MeshObjects/_Vertices/_Indices: CreateComputeBuffer x3 + SetBuffer
+ * (RayTracingMaster.cs:410-412,537-539).  vertices = n_vertices*3 floats, object
+ * space; indices already offset by each mesh's first vertex
+ * (RayTracingMaster.cs:399).  Transforms every triangle to world space once and
+ * (re)builds the acceleration structure.  n_objects == 0 is valid. */
+int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects,
+                  const float *vertices, int n_vertices,
+                  const int32_t *indices, int n_indices);
+
+/* Same geometry, new localToWorld matrices (what a transform change costs the
+ * reference: a full re-upload, RayTracingMaster.cs:254-262,371-413). */
+int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_objects);
+
+/* _SkyboxTexture (RayTracingMaster.cs:457): RGBA float32, w*h texels, row 0 at
+ * v = 0; sampled bilinearly with Repeat wrap at mip 0 (RayTracingShader.compute:331). */
+int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height);
+
+/* InitRenderTexture (RayTracingMaster.cs:542-583): allocate Result / converged
+ * / hit-id targets of width*height, zero-filled. */
+int pt_resize(pt_context *ctx, int width, int height);
+
+/* SetTexture(0, "Result"/"Result1", rt) (RayTracingMaster.cs:740-741) for a
+ * target the CALLER owns in device memory (width*height*16 bytes; hit ids
+ * width*height*4).  NULL re-binds the context's own buffer. */
+int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
+
+/* SetShaderParameters + Dispatch(0, ceil(W/32), ceil(H/32), 1)
+ * (RayTracingMaster.cs:716,745-747). */
+int pt_render(pt_context *ctx, const PtFrameParams *params);
+
+int pt_sync(pt_context *ctx);
+
+/* Read-backs (the reference never reads back on the live path; its unused
+ * helper is toTexture2D, RayTracingMaster.cs:599-607). */
+int pt_read_result(pt_context *ctx, float *rgba_out);
+int pt_read_converged(pt_context *ctx, float *rgba_out);
+int pt_write_converged(pt_context *ctx, const float *rgba_in);
+int pt_read_hit_ids(pt_context *ctx, int32_t *ids_out);
+
+int pt_get_stats(pt_context *ctx, PtStats *out);
+
+/* Trace caller-supplied rays (origin xyz, direction xyz per ray) through the
+ * scene with the kernels' traversal, or (brute_force != 0) with a plain loop
+ * over every primitive on the device in the reference's visiting order
+ * (RayTracingShader.compute:262-285).  Outputs per ray: hit id (-1 miss,
+ * 0 ground plane, 1+i sphere i, 1+n_spheres+k triangle k) and distance
+ * (+inf on miss).  No counterpart in the reference; exists so the
+ * acceleration structure can be checked against the exhaustive loop. */
+int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays,
+                  int brute_force, int32_t *ids_out, float *t_out);
+
+const char *pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRACE_H */

@@ -1,0 +1,571 @@
+/*
+ * pt_oracle.c - CPU oracle for libptrace.  TEST INFRASTRUCTURE ONLY; see
+ * pt_oracle.h for what it is, who may load it, and why parity is unpinned.
+ *
+ * SH = Assets/Scripts/RayTracingShader.compute, ADD = Assets/Shaders/AddMat.shader
+ * of the reference.  Every function names the lines it follows.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -mfma -fopenmp (see Makefile).
+ */
+#include "pt_oracle.h"
+#include "../include/ptrace_fmath.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef pt_f3 f3;
+
+/* ------------------------------------------------------------------ types */
+
+typedef struct Ray { f3 origin, direction, energy; } Ray;        /* SH:92-97 */
+
+typedef struct RayHit {                                          /* SH:126-135 */
+    f3 position; float distance; f3 normal; f3 albedo; f3 specular; float smoothness; f3 emission;
+    int32_t id; /* not in the shader: -1 miss, 0 plane, 1+i sphere i, 1+nS+k triangle k */
+} RayHit;
+
+typedef struct Tri { f3 v0, v1, v2; } Tri;
+
+typedef struct ONode { float lo[3], hi[3]; int32_t left, right; int32_t first, count; } ONode;
+
+struct PtoPrepared {
+    PtSphere *spheres; int32_t n_spheres;
+    Tri *tris; int32_t n_tris;           /* world space, reference order */
+    float *sky; int32_t sky_w, sky_h;
+    int accel;
+    ONode *nodes; int32_t n_nodes; int32_t *order; /* BVH over prim ids 1.. (spheres then tris) */
+};
+
+typedef struct RngState { float seed; float px, py; } RngState;  /* _Seed, _Pixel  SH:47-48 */
+
+typedef struct Counters { uint64_t trace_calls, rays, paths, prims; } Counters;
+
+/* ------------------------------------------------------------- utilities */
+
+static float sdot(f3 x, f3 y, float f) { return pt_saturate(pt_dot3(x, y) * f); }      /* SH:34-37 */
+static float energy(f3 c) { float k = 1.0f / 3.0f; return pt_dot3(c, pt_make3(k, k, k)); } /* SH:39-42 */
+
+/* SH:50-55 */
+static float rng(RngState *s)
+{
+    float d = pt_fma(s->py, 78.233f, s->px * 12.9898f); /* dot(_Pixel, float2(12.9898, 78.233)) */
+    float result = pt_frac(pt_sin(s->seed / 100.0f * d) * 43758.5453f);
+    s->seed += 1.0f;
+    return result;
+}
+
+static Ray create_ray(f3 o, f3 d) { Ray r; r.origin = o; r.direction = d; r.energy = pt_make3(1, 1, 1); return r; } /* SH:99-106 */
+
+/* SH:108-120 */
+static Ray create_camera_ray(const float *c2w, const float *ip, float u, float v)
+{
+    f3 origin = pt_make3(c2w[12], c2w[13], c2w[14]); /* mul(_CameraToWorld, (0,0,0,1)).xyz */
+    /* mul(_CameraInverseProjection, float4(uv, 0, 1)).xyz */
+    f3 d;
+    d.x = pt_fma(ip[4], v, ip[0] * u) + ip[12];
+    d.y = pt_fma(ip[5], v, ip[1] * u) + ip[13];
+    d.z = pt_fma(ip[6], v, ip[2] * u) + ip[14];
+    d = pt_mul_dir(c2w, d);
+    d = pt_normalize3(d);
+    return create_ray(origin, d);
+}
+
+/* SH:137-148 */
+static RayHit create_ray_hit(void)
+{
+    RayHit h; memset(&h, 0, sizeof h);
+    h.distance = PT_INF; h.id = -1;
+    return h;
+}
+
+/* ---------------------------------------------------------- intersection */
+
+/* SH:154-168 */
+static void intersect_ground_plane(const Ray *ray, RayHit *best)
+{
+    float t = -ray->origin.y / ray->direction.y;
+    if (t > 0 && t < best->distance) {
+        best->distance = t;
+        best->position = pt_along3(ray->origin, t, ray->direction);
+        best->normal = pt_make3(0, 1, 0);
+        best->albedo = pt_make3(0.5f, 0.5f, 0.5f);
+        best->specular = pt_make3(0.03f, 0.03f, 0.03f);
+        best->smoothness = 0.2f;
+        best->emission = pt_make3(0, 0, 0);
+        best->id = 0;
+    }
+}
+
+/* SH:170-190.  `id` only labels the hit. */
+static void intersect_sphere(const Ray *ray, RayHit *best, const PtSphere *s, int32_t id, int lexi)
+{
+    f3 c = pt_make3(s->position[0], s->position[1], s->position[2]);
+    f3 d = pt_sub3(ray->origin, c);
+    float p1 = -pt_dot3(ray->direction, d);
+    float p2sqr = p1 * p1 - pt_dot3(d, d) + s->radius * s->radius;
+    if (p2sqr < 0) return;
+    float p2 = pt_sqrt(p2sqr);
+    float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
+    if (t > 0 && (t < best->distance || (lexi && t == best->distance && id < best->id))) {
+        best->distance = t;
+        best->position = pt_along3(ray->origin, t, ray->direction);
+        best->normal = pt_normalize3(pt_sub3(best->position, c));
+        best->albedo = pt_make3(s->albedo[0], s->albedo[1], s->albedo[2]);
+        best->specular = pt_make3(s->specular[0], s->specular[1], s->specular[2]);
+        best->smoothness = s->smoothness;
+        best->emission = pt_make3(s->emission[0], s->emission[1], s->emission[2]);
+        best->id = id;
+    }
+}
+
+/* SH:192-230 */
+static int intersect_triangle_mt97(const Ray *ray, f3 vert0, f3 vert1, f3 vert2, float *t, float *u, float *v)
+{
+    f3 edge1 = pt_sub3(vert1, vert0);
+    f3 edge2 = pt_sub3(vert2, vert0);
+    f3 pvec = pt_cross3(ray->direction, edge2);
+    float det = pt_dot3(edge1, pvec);
+    if (det < PT_EPSILON) return 0;          /* backface culling */
+    float inv_det = 1.0f / det;
+    f3 tvec = pt_sub3(ray->origin, vert0);
+    *u = pt_dot3(tvec, pvec) * inv_det;
+    if (*u < 0.0f || *u > 1.0f) return 0;
+    f3 qvec = pt_cross3(tvec, edge1);
+    *v = pt_dot3(ray->direction, qvec) * inv_det;
+    if (*v < 0.0f || *u + *v > 1.0f) return 0;
+    *t = pt_dot3(edge2, qvec) * inv_det;
+    return 1;
+}
+
+/* Body of the loop at SH:236-256 for one triangle already in world space (the
+ * shader re-applies localToWorldMatrix per ray, SH:238-240; pto_prepare applies
+ * the same pt_mul_point once, which yields the same bits). */
+static void intersect_tri(const Ray *ray, RayHit *best, const Tri *tr, int32_t id, int lexi)
+{
+    float t, u, v;
+    if (intersect_triangle_mt97(ray, tr->v0, tr->v1, tr->v2, &t, &u, &v)) {
+        if (t > 0 && (t < best->distance || (lexi && t == best->distance && id < best->id))) {
+            best->distance = t;
+            best->position = pt_along3(ray->origin, t, ray->direction);
+            best->normal = pt_normalize3(pt_cross3(pt_sub3(tr->v1, tr->v0), pt_sub3(tr->v2, tr->v0)));
+            best->albedo = pt_make3(0, 0, 0);
+            best->specular = pt_make3(0.65f, 0.65f, 0.65f);
+            best->smoothness = 0.99f;
+            best->emission = pt_make3(0, 0, 0);
+            best->id = id;
+        }
+    }
+}
+
+/* The oracle's own acceleration structure (accel != 0): a median-split BVH
+ * over spheres and triangles.  Not in the reference.  It prunes with padded
+ * boxes and picks the winner by (distance, id) - the same winner the
+ * exhaustive strict-less-than loop in id order picks. */
+static int box_hit(const ONode *n, const Ray *ray, f3 inv, float best)
+{
+    float tx0 = (n->lo[0] - ray->origin.x) * inv.x, tx1 = (n->hi[0] - ray->origin.x) * inv.x;
+    float ty0 = (n->lo[1] - ray->origin.y) * inv.y, ty1 = (n->hi[1] - ray->origin.y) * inv.y;
+    float tz0 = (n->lo[2] - ray->origin.z) * inv.z, tz1 = (n->hi[2] - ray->origin.z) * inv.z;
+    float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    return tmin <= tmax * 1.000002f + 1e-30f && tmin <= best;
+}
+
+static void trace_bvh(const PtoPrepared *p, const Ray *ray, RayHit *best, Counters *cn)
+{
+    if (p->n_nodes == 0) return;
+    f3 inv = pt_make3(1.0f / ray->direction.x, 1.0f / ray->direction.y, 1.0f / ray->direction.z);
+    int32_t stack[128]; int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const ONode *n = &p->nodes[stack[--sp]];
+        if (!box_hit(n, ray, inv, best->distance)) continue;
+        if (n->count) {
+            for (int32_t k = 0; k < n->count; k++) {
+                int32_t id = p->order[n->first + k];
+                cn->prims++;
+                if (id <= p->n_spheres) intersect_sphere(ray, best, &p->spheres[id - 1], id, 1);
+                else intersect_tri(ray, best, &p->tris[id - 1 - p->n_spheres], id, 1);
+            }
+        } else {
+            stack[sp++] = n->left; stack[sp++] = n->right;
+        }
+    }
+}
+
+/* SH:262-285 */
+static RayHit trace(const PtoPrepared *p, const Ray *ray, Counters *cn)
+{
+    RayHit best = create_ray_hit();
+    cn->trace_calls++;
+    intersect_ground_plane(ray, &best);
+    if (p->accel) { trace_bvh(p, ray, &best, cn); return best; }
+    for (int32_t i = 0; i < p->n_spheres; i++)
+        intersect_sphere(ray, &best, &p->spheres[i], 1 + i, 0);
+    /* mesh objects in order, triangles in order: p->tris is that flattened order */
+    for (int32_t k = 0; k < p->n_tris; k++)
+        intersect_tri(ray, &best, &p->tris[k], 1 + p->n_spheres + k, 0);
+    cn->prims += (uint64_t)p->n_spheres + (uint64_t)p->n_tris;
+    return best;
+}
+
+/* ---------------------------------------------------------------- sampling */
+
+/* SH:291-302; rows tangent, binormal, normal */
+static void get_tangent_space(f3 normal, f3 *tangent, f3 *binormal)
+{
+    f3 helper = pt_make3(1, 0, 0);
+    if (pt_abs(normal.x) > 0.99f) helper = pt_make3(0, 0, 1);
+    *tangent = pt_normalize3(pt_cross3(normal, helper));
+    *binormal = pt_normalize3(pt_cross3(normal, *tangent));
+}
+
+/* SH:304-314 */
+static f3 sample_hemisphere(RngState *rs, f3 normal, float alpha)
+{
+    float cosTheta = pt_pow(rng(rs), 1.0f / (alpha + 1.0f));
+    float sinTheta = pt_sqrt(1.0f - cosTheta * cosTheta);
+    float phi = 2 * PT_PI * rng(rs);
+    f3 ts = pt_make3(pt_cos(phi) * sinTheta, pt_sin(phi) * sinTheta, cosTheta);
+    f3 tangent, binormal;
+    get_tangent_space(normal, &tangent, &binormal);
+    /* mul(tangentSpaceDir, float3x3(tangent, binormal, normal)): row vector times matrix */
+    f3 r;
+    r.x = pt_fma(ts.z, normal.x, pt_fma(ts.y, binormal.x, ts.x * tangent.x));
+    r.y = pt_fma(ts.z, normal.y, pt_fma(ts.y, binormal.y, ts.x * tangent.y));
+    r.z = pt_fma(ts.z, normal.z, pt_fma(ts.y, binormal.z, ts.x * tangent.z));
+    return r;
+}
+
+static float smoothness_to_phong_alpha(float s) { return pt_pow(1000.0f, s * s); } /* SH:319-322 */
+
+/* _SkyboxTexture.SampleLevel(sampler, uv, 0): bilinear, Repeat wrap on both
+ * axes, texel centres at (i+0.5)/N, weights in fp32; lerp(a,b,t) = a + t*(b-a). */
+static int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+static f3 sky_fetch(const PtoPrepared *p, float u, float v)
+{
+    if (!p->sky) return pt_make3(0, 0, 0);
+    int W = p->sky_w, H = p->sky_h;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float x0f = pt_floor(x), y0f = pt_floor(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapi((int)x0f, W), y0 = wrapi((int)y0f, H);
+    int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
+    const float *c00 = p->sky + 4 * ((size_t)y0 * W + x0), *c10 = p->sky + 4 * ((size_t)y0 * W + x1);
+    const float *c01 = p->sky + 4 * ((size_t)y1 * W + x0), *c11 = p->sky + 4 * ((size_t)y1 * W + x1);
+    float out[3];
+    for (int k = 0; k < 3; k++) {
+        float a = c00[k] + fx * (c10[k] - c00[k]);
+        float b = c01[k] + fx * (c11[k] - c01[k]);
+        out[k] = a + fy * (b - a);
+    }
+    return pt_make3(out[0], out[1], out[2]);
+}
+
+/* SH:324-332 */
+static f3 skybox_sample(const PtoPrepared *p, Ray *ray)
+{
+    ray->energy = pt_make3(0, 0, 0);
+    float theta = pt_acos(ray->direction.y) / -PT_PI;
+    float phi = pt_atan2(ray->direction.x, -ray->direction.z) / -PT_PI * 0.5f;
+    return pt_scale3(sky_fetch(p, phi, theta), 2.0f);
+}
+
+/* SH:334-373 */
+static f3 shade(const PtoPrepared *p, RngState *rs, Ray *ray, RayHit hit)
+{
+    if (hit.distance < PT_INF) {
+        hit.albedo = pt_make3(pt_min(1.0f - hit.specular.x, hit.albedo.x),
+                              pt_min(1.0f - hit.specular.y, hit.albedo.y),
+                              pt_min(1.0f - hit.specular.z, hit.albedo.z));
+        float specChance = energy(hit.specular);
+        float diffChance = energy(hit.albedo);
+        float roulette = rng(rs);
+        if (roulette < specChance) {
+            ray->origin = pt_along3(hit.position, 0.001f, hit.normal); /* position + normal*0.001 */
+            float alpha = smoothness_to_phong_alpha(hit.smoothness);
+            ray->direction = sample_hemisphere(rs, pt_reflect3(ray->direction, hit.normal), alpha);
+            float f = (alpha + 2) / (alpha + 1);
+            float k = (1.0f / specChance);
+            float sd = sdot(hit.normal, ray->direction, f);
+            /* ray.energy *= (1/specChance) * hit.specular * sdot(...), left to right */
+            ray->energy.x *= (k * hit.specular.x) * sd;
+            ray->energy.y *= (k * hit.specular.y) * sd;
+            ray->energy.z *= (k * hit.specular.z) * sd;
+        } else if (diffChance > 0 && roulette < specChance + diffChance) {
+            ray->origin = pt_along3(hit.position, 0.001f, hit.normal);
+            ray->direction = sample_hemisphere(rs, hit.normal, 1.0f);
+            float k = (1.0f / diffChance);
+            ray->energy.x *= k * hit.albedo.x;
+            ray->energy.y *= k * hit.albedo.y;
+            ray->energy.z *= k * hit.albedo.z;
+        } else {
+            ray->energy = pt_make3(0, 0, 0);
+        }
+        return hit.emission;
+    }
+    return skybox_sample(p, ray);
+}
+
+/* ------------------------------------------------------------------ kernel */
+
+static int any3(f3 v) { return v.x != 0.0f || v.y != 0.0f || v.z != 0.0f; }
+
+/* CSMain for one thread id, renderMode == 1: SH:725-731 (the Result1 copy is
+ * the host's business here), SH:798-809, SH:822-874, SH:933-936. */
+static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, int idx, int idy,
+                    float *out4, int32_t *hit_id, Counters *cn)
+{
+    float fw = (float)W, fh = (float)H;
+    float u = (float)idx / fw * 2.0f - 1.0f;   /* SH:802, SH:842: pixel corner, no jitter */
+    float v = (float)idy / fh * 2.0f - 1.0f;
+    if (prm->depth == 1) {                     /* SH:799-809 */
+        Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
+        RayHit hit = trace(p, &ray, cn);
+        cn->rays++; cn->paths++;
+        float dis = hit.distance / 16.0f;
+        out4[0] = out4[1] = out4[2] = out4[3] = dis;
+        if (hit_id) *hit_id = hit.id;
+        return;
+    }
+    f3 result = pt_make3(0, 0, 0);
+    RngState rs; rs.seed = prm->seed; rs.px = (float)idx * 2.0f; rs.py = (float)idy * 2.0f; /* SH:831 */
+    int spp = prm->samples_per_pixel;
+    float fspp = (float)spp;
+    int maxb = prm->max_bounces;
+    f3 camo = pt_make3(prm->camera_to_world[12], prm->camera_to_world[13], prm->camera_to_world[14]);
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; /* spp <= 0: the shader writes nothing; targets start zeroed */
+    for (int j = 1; j < spp + 1; j++) {            /* SH:839 */
+        Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
+        cn->paths++;
+        RayHit hit = trace(p, &ray, cn);           /* SH:859 */
+        cn->rays++;
+        f3 hitPos = hit.position;                  /* SH:860; (0,0,0) on a miss */
+        if (hit_id) *hit_id = hit.id;
+        int primary_miss = !(hit.distance < PT_INF);
+        {   /* SH:866: energy is read before Shade() changes it */
+            f3 e = ray.energy;
+            f3 s = shade(p, &rs, &ray, hit);
+            result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+        }
+        for (int i = 1; i < maxb; i++) {           /* SH:867 (4 in the shader) */
+            hit = trace(p, &ray, cn);
+            if (!(i == 1 && primary_miss)) cn->rays++;
+            f3 e = ray.energy;
+            f3 s = shade(p, &rs, &ray, hit);
+            result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+            if (!any3(ray.energy)) break;          /* SH:871 */
+        }
+        /* SH:933-936 */
+        out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
+        out4[3] = pt_length3(pt_sub3(hitPos, camo));
+    }
+}
+
+int pto_render(const PtoPrepared *p, const PtFrameParams *prm, int W, int H,
+               float *result, int32_t *hit_ids, PtoStats *stats, int threads)
+{
+    if (!p || !prm || !result || W <= 0 || H <= 0 || prm->max_bounces < 1) return 1;
+    int x0 = 0, y0 = 0, tw = W, th = H;
+    if (prm->tile_w > 0 && prm->tile_h > 0) { x0 = prm->tile_x0; y0 = prm->tile_y0; tw = prm->tile_w; th = prm->tile_h; }
+    if (x0 < 0 || y0 < 0 || x0 + tw > W || y0 + th > H) return 1;
+    if (threads <= 0) threads = 1;
+    uint64_t a = 0, b = 0, c = 0, d = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a, b, c, d)
+    for (int y = y0; y < y0 + th; y++) {
+        Counters cn = {0, 0, 0, 0};
+        for (int x = x0; x < x0 + tw; x++) {
+            size_t px = (size_t)y * W + x;
+            cs_main(p, prm, W, H, x, y, result + 4 * px, hit_ids ? hit_ids + px : NULL, &cn);
+        }
+        a += cn.trace_calls; b += cn.rays; c += cn.paths; d += cn.prims;
+    }
+    if (stats) { stats->trace_calls = a; stats->rays = b; stats->paths = c; stats->prims_tested = d; }
+    return 0;
+}
+
+/* ------------------------------------------------------------ accumulation */
+
+/* ADD:44-63 with Blend SrcAlpha OneMinusSrcAlpha (ADD:11).  Roles: the sampled
+ * _MainTex is the history (converged image), the blend destination is the
+ * fresh frame; the blended value is the new converged image. */
+void pto_accumulate(int mode, uint32_t sample_index, const float *fresh, float *conv, int64_t n)
+{
+    float S = (float)sample_index;
+    for (int64_t i = 0; i < n; i++) {
+        const float *f = fresh + 4 * i; float *h = conv + 4 * i;
+        if (mode == PT_ACCUM_MEAN) {
+            float a = 1.0f / (S + 1.0f);
+            for (int k = 0; k < 4; k++) h[k] = f[k] * a + h[k] * (1.0f - a);
+        } else if (mode == PT_ACCUM_SUM) {
+            for (int k = 0; k < 4; k++) h[k] = sample_index == 0 ? f[k] : h[k] + f[k];
+        } else if (mode == PT_ACCUM_ADDMAT) {
+            float alpha = h[3];                                    /* ADD:56 */
+            float firefly = 0.8f;                                  /* ADD:57 */
+            if (h[0] > firefly || h[1] > firefly || h[2] > firefly) alpha = 0.1f; /* ADD:58-60 */
+            float t = 1.0f + S * alpha;                            /* ADD:62 */
+            float A = 1.0f - 1.0f / t;                             /* ADD:63 */
+            for (int k = 0; k < 3; k++) h[k] = h[k] * A + f[k] * (1.0f - A);
+            h[3] = A * A + f[3] * (1.0f - A);
+        }
+    }
+}
+
+/* ----------------------------------------------------------------- prepare */
+
+static void node_bounds(PtoPrepared *p, const int32_t *ids, int32_t n, float *lo, float *hi, float *clo, float *chi)
+{
+    for (int k = 0; k < 3; k++) { lo[k] = clo[k] = INFINITY; hi[k] = chi[k] = -INFINITY; }
+    for (int32_t i = 0; i < n; i++) {
+        int32_t id = ids[i];
+        float blo[3], bhi[3];
+        if (id <= p->n_spheres) {
+            const PtSphere *s = &p->spheres[id - 1];
+            for (int k = 0; k < 3; k++) { blo[k] = s->position[k] - s->radius; bhi[k] = s->position[k] + s->radius; }
+        } else {
+            const Tri *t = &p->tris[id - 1 - p->n_spheres];
+            const float *a = &t->v0.x, *b = &t->v1.x, *c = &t->v2.x;
+            for (int k = 0; k < 3; k++) { blo[k] = fminf(a[k], fminf(b[k], c[k])); bhi[k] = fmaxf(a[k], fmaxf(b[k], c[k])); }
+        }
+        for (int k = 0; k < 3; k++) {
+            float ce = 0.5f * (blo[k] + bhi[k]);
+            lo[k] = fminf(lo[k], blo[k]); hi[k] = fmaxf(hi[k], bhi[k]);
+            clo[k] = fminf(clo[k], ce); chi[k] = fmaxf(chi[k], ce);
+        }
+    }
+}
+
+static int g_axis; static PtoPrepared *g_p;
+static float centroid(int32_t id, int axis)
+{
+    if (id <= g_p->n_spheres) return g_p->spheres[id - 1].position[axis];
+    const Tri *t = &g_p->tris[id - 1 - g_p->n_spheres];
+    const float *a = &t->v0.x, *b = &t->v1.x, *c = &t->v2.x;
+    return 0.5f * (fminf(a[axis], fminf(b[axis], c[axis])) + fmaxf(a[axis], fmaxf(b[axis], c[axis])));
+}
+static int cmp_centroid(const void *x, const void *y)
+{
+    float a = centroid(*(const int32_t *)x, g_axis), b = centroid(*(const int32_t *)y, g_axis);
+    return (a > b) - (a < b);
+}
+
+static int32_t build_node(PtoPrepared *p, int32_t first, int32_t n, float pad)
+{
+    int32_t me = p->n_nodes++;
+    float lo[3], hi[3], clo[3], chi[3];
+    node_bounds(p, p->order + first, n, lo, hi, clo, chi);
+    ONode *nd = &p->nodes[me];
+    for (int k = 0; k < 3; k++) { nd->lo[k] = lo[k] - pad; nd->hi[k] = hi[k] + pad; }
+    nd->first = first; nd->count = 0; nd->left = nd->right = -1;
+    int axis = 0;
+    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+    if (n <= 4 || !(chi[axis] > clo[axis])) { nd->count = n; return me; }
+    g_axis = axis; g_p = p;
+    qsort(p->order + first, (size_t)n, sizeof(int32_t), cmp_centroid);
+    int32_t half = n / 2;
+    int32_t l = build_node(p, first, half, pad);
+    int32_t r = build_node(p, first + half, n - half, pad);
+    p->nodes[me].left = l; p->nodes[me].right = r;
+    return me;
+}
+
+PtoPrepared *pto_prepare(const PtoScene *sc, int accel)
+{
+    PtoPrepared *p = (PtoPrepared *)calloc(1, sizeof *p);
+    if (!p) return NULL;
+    p->accel = accel;
+    p->n_spheres = sc->n_spheres;
+    if (sc->n_spheres > 0) {
+        p->spheres = (PtSphere *)malloc(sizeof(PtSphere) * (size_t)sc->n_spheres);
+        memcpy(p->spheres, sc->spheres, sizeof(PtSphere) * (size_t)sc->n_spheres);
+    }
+    /* flatten mesh objects in order, triangles in order (SH:278-282, SH:236) */
+    int64_t nt = 0;
+    for (int32_t o = 0; o < sc->n_objects; o++) nt += sc->objects[o].indices_count / 3;
+    p->n_tris = (int32_t)nt;
+    if (nt > 0) p->tris = (Tri *)malloc(sizeof(Tri) * (size_t)nt);
+    int64_t k = 0;
+    for (int32_t o = 0; o < sc->n_objects; o++) {
+        const PtMeshObject *mo = &sc->objects[o];
+        for (int32_t i = mo->indices_offset; i + 2 < mo->indices_offset + mo->indices_count; i += 3) {
+            const float *a = sc->vertices + 3 * (size_t)sc->indices[i];
+            const float *b = sc->vertices + 3 * (size_t)sc->indices[i + 1];
+            const float *c = sc->vertices + 3 * (size_t)sc->indices[i + 2];
+            p->tris[k].v0 = pt_mul_point(mo->local_to_world, pt_make3(a[0], a[1], a[2])); /* SH:238-240 */
+            p->tris[k].v1 = pt_mul_point(mo->local_to_world, pt_make3(b[0], b[1], b[2]));
+            p->tris[k].v2 = pt_mul_point(mo->local_to_world, pt_make3(c[0], c[1], c[2]));
+            k++;
+        }
+    }
+    p->n_tris = (int32_t)k;
+    if (sc->sky && sc->sky_w > 0 && sc->sky_h > 0) {
+        size_t n = (size_t)sc->sky_w * sc->sky_h * 4;
+        p->sky = (float *)malloc(n * sizeof(float));
+        memcpy(p->sky, sc->sky, n * sizeof(float));
+        p->sky_w = sc->sky_w; p->sky_h = sc->sky_h;
+    }
+    int32_t np = p->n_spheres + p->n_tris;
+    if (accel && np > 0) {
+        p->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)np);
+        for (int32_t i = 0; i < np; i++) p->order[i] = i + 1;
+        p->nodes = (ONode *)malloc(sizeof(ONode) * (size_t)(2 * np));
+        float lo[3], hi[3], clo[3], chi[3];
+        node_bounds(p, p->order, np, lo, hi, clo, chi);
+        float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        build_node(p, 0, np, 1e-5f * diag + 1e-6f);
+    }
+    return p;
+}
+
+void pto_release(PtoPrepared *p)
+{
+    if (!p) return;
+    free(p->spheres); free(p->tris); free(p->sky); free(p->nodes); free(p->order); free(p);
+}
+
+/* ------------------------------------------------------ pieces for KATs */
+
+void pto_rand_sequence(float seed, int idx, int idy, int n, float *out)
+{
+    RngState rs; rs.seed = seed; rs.px = (float)idx * 2.0f; rs.py = (float)idy * 2.0f;
+    for (int i = 0; i < n; i++) out[i] = rng(&rs);
+}
+
+void pto_camera_ray(const float *c2w, const float *ip, int idx, int idy, int W, int H, float *od)
+{
+    float u = (float)idx / (float)W * 2.0f - 1.0f, v = (float)idy / (float)H * 2.0f - 1.0f;
+    Ray r = create_camera_ray(c2w, ip, u, v);
+    od[0] = r.origin.x; od[1] = r.origin.y; od[2] = r.origin.z;
+    od[3] = r.direction.x; od[4] = r.direction.y; od[5] = r.direction.z;
+}
+
+void pto_trace_ray(const PtoPrepared *p, const float *od, int32_t *id, float *t)
+{
+    Counters cn = {0, 0, 0, 0};
+    Ray r = create_ray(pt_make3(od[0], od[1], od[2]), pt_make3(od[3], od[4], od[5]));
+    RayHit h = trace(p, &r, &cn);
+    *id = h.id; *t = h.distance;
+}
+
+void pto_sky_sample(const PtoPrepared *p, const float *d, float *rgb)
+{
+    Ray r = create_ray(pt_make3(0, 0, 0), pt_make3(d[0], d[1], d[2]));
+    f3 c = skybox_sample(p, &r);
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+
+float pto_fmath(int which, float a, float b)
+{
+    switch (which) {
+    case 0: return pt_sin(a);
+    case 1: return pt_cos(a);
+    case 2: return pt_pow(a, b);
+    case 3: return pt_acos(a);
+    case 4: return pt_atan2(a, b);
+    case 5: return pt_log2(a);
+    case 6: return pt_exp2(a);
+    default: return 0.0f;
+    }
+}

@@ -1,0 +1,73 @@
+/*
+ * pt_oracle.h - CPU oracle for libptrace.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A scalar restatement, in plain C, of the plain path-trace mode of
+ * Assets/Scripts/RayTracingShader.compute (kernel CSMain) and of
+ * Assets/Shaders/AddMat.shader, written line by line from those files.  It is
+ * the checker the HIP kernels are compared with; nothing in the product links
+ * or calls it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden images or known-answer
+ * vectors, and its implementation (HLSL run by the Unity editor, driven by C#)
+ * cannot be built or run where this was written.  The oracle is therefore
+ * pinned only by analytic known-answer tests (tests/test_oracle_kat.py) and by
+ * reading it against the cited shader lines; HLSL intrinsics are taken from
+ * include/ptrace_fmath.h, which fixes the precision the shader leaves open.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+#include "../include/ptrace.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtoScene {
+    const PtSphere *spheres;      int32_t n_spheres;
+    const PtMeshObject *objects;  int32_t n_objects;
+    const float *vertices;        int32_t n_vertices;
+    const int32_t *indices;       int32_t n_indices;
+    const float *sky;             int32_t sky_w, sky_h;   /* RGBA32F; NULL = black sky */
+} PtoScene;
+
+typedef struct PtoStats {
+    uint64_t trace_calls;        /* every Trace() the shader would execute                         */
+    uint64_t rays;               /* the same minus the re-trace of an unchanged ray after a primary
+                                    miss (RayTracingShader.compute:866-870), which cannot change the
+                                    image; this is the count the HIP kernels report                */
+    uint64_t paths;              /* camera rays (pixels * samples)                                 */
+    uint64_t prims_tested;       /* sphere + triangle tests                                        */
+} PtoStats;
+
+/* Opaque prepared scene: world-space triangles (and, with accel != 0, the
+ * oracle's own median-split BVH). accel == 0 is the reference's exhaustive
+ * loop over every primitive (RayTracingShader.compute:262-285). */
+typedef struct PtoPrepared PtoPrepared;
+PtoPrepared *pto_prepare(const PtoScene *scene, int accel);
+void pto_release(PtoPrepared *p);
+
+/* CSMain, plain mode, over the tile named in `params` (whole image when the
+ * tile is empty).  result: W*H*4 floats, only tile pixels are written.
+ * hit_ids (may be NULL): W*H primary-hit ids.  threads: OpenMP threads (rows
+ * are independent); <= 0 means 1. */
+int pto_render(const PtoPrepared *p, const PtFrameParams *params, int width, int height,
+               float *result, int32_t *hit_ids, PtoStats *stats, int threads);
+
+/* AddMat.shader / running mean / sum: same modes as PtFrameParams.accumulate. */
+void pto_accumulate(int mode, uint32_t sample_index, const float *fresh, float *converged, int64_t n_pixels);
+
+/* Pieces exposed for known-answer tests. */
+void pto_rand_sequence(float seed, int id_x, int id_y, int n, float *out);           /* SH:47-55,831 */
+void pto_camera_ray(const float *cam_to_world, const float *cam_inv_proj,
+                    int id_x, int id_y, int width, int height, float *origin_dir6); /* SH:108-120,842 */
+void pto_trace_ray(const PtoPrepared *p, const float *origin_dir6, int32_t *id_out, float *t_out);
+void pto_sky_sample(const PtoPrepared *p, const float *dir3, float *rgb_out);        /* SH:324-332 */
+float pto_fmath(int which, float a, float b); /* 0 sin 1 cos 2 pow 3 acos 4 atan2 5 log2 6 exp2 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,14 @@
+"""pathtracing_amd - MI355X-native path-tracing hot path of VirtualEngineeringLab/Pathtracing.
+
+The product is csrc/libptrace.so (HIP kernels for gfx950 behind the C ABI of
+include/ptrace.h) and host/libptmaster.so (C++ mirror of the reference's C#
+host).  This package is the ctypes harness over both.
+"""
+from ._ffi import (PT_ACCUM_ADDMAT, PT_ACCUM_MEAN, PT_ACCUM_NONE, PT_ACCUM_SUM, PT_TARGET_CONVERGED,
+                   PT_TARGET_HIT_IDS, PT_TARGET_RESULT, PtFrameParams, PtMeshObject, PtSphere, PtStats)
+from .scenes import Scene, camera_matrices, frame_seed, make_params, procedural_sky
+from .tracer import PathTracer, PtraceError
+
+__all__ = ["PathTracer", "PtraceError", "Scene", "camera_matrices", "frame_seed", "make_params", "procedural_sky",
+           "PtFrameParams", "PtMeshObject", "PtSphere", "PtStats", "PT_ACCUM_NONE", "PT_ACCUM_MEAN", "PT_ACCUM_SUM",
+           "PT_ACCUM_ADDMAT", "PT_TARGET_RESULT", "PT_TARGET_CONVERGED", "PT_TARGET_HIT_IDS"]

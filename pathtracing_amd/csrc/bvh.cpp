@@ -1,0 +1,213 @@
+// Binned-SAH BVH builder (host, multi-threaded).  See bvh.hpp.
+#include "bvh.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace ptrace {
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+struct Tmp {
+    Aabb box;
+    int32_t left = -1, right = -1;
+    uint32_t first = 0, count = 0;  // count > 0: leaf
+};
+
+inline void box_reset(Aabb &b)
+{
+    for (int k = 0; k < 3; k++) { b.lo[k] = kInf; b.hi[k] = -kInf; }
+}
+inline void box_grow(Aabb &b, const Aabb &o)
+{
+    for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); }
+}
+inline float box_area(const Aabb &b)
+{
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+inline float centroid(const Aabb &b, int axis) { return 0.5f * (b.lo[axis] + b.hi[axis]); }
+
+struct Builder {
+    const std::vector<Aabb> &boxes;
+    std::vector<uint32_t> &order;
+    std::vector<Tmp> tmp;
+    std::atomic<int32_t> next{0};
+    std::atomic<int> live_threads{1};
+    std::atomic<int> max_depth{0};
+    int leaf_size;
+    int max_threads;
+
+    Builder(const std::vector<Aabb> &b, std::vector<uint32_t> &o, int leaf, int thr)
+        : boxes(b), order(o), tmp(2 * b.size() + 1), leaf_size(leaf), max_threads(thr) {}
+
+    static int levels_needed(uint32_t n, int leaf)
+    {
+        int l = 0;
+        uint64_t cap = (uint64_t)leaf;
+        while (cap < n) { cap <<= 1; l++; }
+        return l;
+    }
+
+    int32_t build(uint32_t first, uint32_t n, int depth)
+    {
+        int32_t me = next.fetch_add(1);
+        Tmp &node = tmp[me];
+        Aabb box, cbox;
+        box_reset(box); box_reset(cbox);
+        for (uint32_t i = first; i < first + n; i++) {
+            const Aabb &b = boxes[order[i]];
+            box_grow(box, b);
+            for (int k = 0; k < 3; k++) {
+                float c = centroid(b, k);
+                cbox.lo[k] = std::min(cbox.lo[k], c); cbox.hi[k] = std::max(cbox.hi[k], c);
+            }
+        }
+        node.box = box; node.first = first; node.count = 0;
+        int d = max_depth.load();
+        while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+
+        if (n <= (uint32_t)leaf_size) { node.count = n; return me; }
+
+        // Once the remaining depth budget only just fits a balanced tree over
+        // n primitives, stop using SAH and halve the range.
+        bool force_median = depth + levels_needed(n, leaf_size) + 2 >= kMaxDepth;
+        uint32_t mid = first + n / 2;
+        bool split_done = false;
+
+        if (!force_median) {
+            float best_cost = kInf; int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
+                if (!(ext > 0.0f)) continue;
+                float scale = (float)kBins / ext;
+                Aabb bb[kBins]; uint32_t cnt[kBins];
+                for (int b = 0; b < kBins; b++) { box_reset(bb[b]); cnt[b] = 0; }
+                for (uint32_t i = first; i < first + n; i++) {
+                    const Aabb &pb = boxes[order[i]];
+                    int b = (int)((centroid(pb, axis) - lo) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    box_grow(bb[b], pb); cnt[b]++;
+                }
+                float right_area[kBins]; uint32_t right_cnt[kBins];
+                Aabb acc; box_reset(acc); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; b--) {
+                    box_grow(acc, bb[b]); c += cnt[b];
+                    right_area[b] = box_area(acc); right_cnt[b] = c;
+                }
+                box_reset(acc); c = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    box_grow(acc, bb[b]); c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = box_area(acc) * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - lo;
+                float scale = (float)kBins / ext;
+                auto it = std::partition(order.begin() + first, order.begin() + first + n, [&](uint32_t id) {
+                    int b = (int)((centroid(boxes[id], best_axis) - lo) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - order.begin());
+                split_done = mid > first && mid < first + n;
+            }
+        }
+        if (!split_done) {
+            // median split along the widest centroid axis (or plain halving when all centroids coincide)
+            int axis = 0;
+            for (int k = 1; k < 3; k++)
+                if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
+            mid = first + n / 2;
+            if (cbox.hi[axis] > cbox.lo[axis])
+                std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + n,
+                                 [&](uint32_t a, uint32_t b) { return centroid(boxes[a], axis) < centroid(boxes[b], axis); });
+        }
+
+        uint32_t nl = mid - first, nr = n - nl;
+        int32_t l, r;
+        bool spawn = nl > 32768 && nr > 32768 && live_threads.load() < max_threads;
+        if (spawn) {
+            live_threads.fetch_add(1);
+            std::thread t([&] { l = build(first, nl, depth + 1); live_threads.fetch_sub(1); });
+            r = build(mid, nr, depth + 1);
+            t.join();
+        } else {
+            l = build(first, nl, depth + 1);
+            r = build(mid, nr, depth + 1);
+        }
+        tmp[me].left = l; tmp[me].right = r;
+        return me;
+    }
+};
+
+inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+}  // namespace
+
+BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads)
+{
+    BvhResult out;
+    const uint32_t n = (uint32_t)boxes.size();
+    if (n == 0) return out;
+    leaf_size = std::max(1, std::min(leaf_size, kMaxLeafPrims));
+    if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    out.order.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.order[i] = i;
+
+    Builder b(boxes, out.order, leaf_size, threads);
+    int32_t root = b.build(0, n, 0);
+    out.depth = b.max_depth.load();
+
+    // Emit the device layout in depth-first order: each inner node carries both children's boxes.
+    const std::vector<Tmp> &tmp = b.tmp;
+    auto set_child = [](float *lo, float *hi, const Aabb *box) {
+        for (int k = 0; k < 3; k++) { lo[k] = box ? box->lo[k] : kInf; hi[k] = box ? box->hi[k] : -kInf; }
+    };
+    if (tmp[root].count > 0) {
+        BvhNode nd; std::memset(&nd, 0, sizeof nd);
+        set_child(nd.llo, nd.lhi, &tmp[root].box);
+        nd.left = encode_leaf(tmp[root].first, tmp[root].count);
+        set_child(nd.rlo, nd.rhi, nullptr);
+        nd.right = encode_leaf(0, 1);
+        out.nodes.push_back(nd);
+        out.depth = 1;
+        return out;
+    }
+    out.nodes.reserve((size_t)b.next.load());
+    struct Item { int32_t tmp_index; int32_t parent; int side; };
+    std::vector<Item> stack;
+    stack.push_back({root, -1, 0});
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        const Tmp &t = tmp[it.tmp_index];
+        int32_t me = (int32_t)out.nodes.size();
+        BvhNode nd; std::memset(&nd, 0, sizeof nd);
+        const Tmp &l = tmp[t.left], &r = tmp[t.right];
+        set_child(nd.llo, nd.lhi, &l.box);
+        set_child(nd.rlo, nd.rhi, &r.box);
+        nd.left = l.count ? encode_leaf(l.first, l.count) : 0;
+        nd.right = r.count ? encode_leaf(r.first, r.count) : 0;
+        out.nodes.push_back(nd);
+        if (it.parent >= 0) {
+            if (it.side == 0) out.nodes[it.parent].left = me; else out.nodes[it.parent].right = me;
+        }
+        // push right first so the left subtree is emitted right after its parent
+        if (!r.count) stack.push_back({t.right, me, 1});
+        if (!l.count) stack.push_back({t.left, me, 0});
+    }
+    out.depth += 1;
+    return out;
+}
+
+}  // namespace ptrace

@@ -1,0 +1,44 @@
+// Host-side BVH construction for libptrace.
+//
+// The reference has no acceleration structure: RayTracingShader.compute:232-257
+// loops over every triangle for every ray.  This builder produces a binary BVH
+// over the scene's spheres and world-space triangles whose closest hit is, by
+// construction of the traversal (padded boxes, (distance, id) ordering), the hit
+// that loop returns.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace ptrace {
+
+struct Aabb {
+    float lo[3], hi[3];
+};
+
+// Device node, 64 bytes = four float4 loads:
+//   q0 = (left.lo.xyz,  bits(left))   q1 = (left.hi.xyz,  bits(right))
+//   q2 = (right.lo.xyz, 0)            q3 = (right.hi.xyz, 0)
+// child >= 0: index of an inner node.  child < 0: leaf, ~child = (first << 3) | (count - 1)
+// over the reordered primitive records.  An absent child has an inverted box
+// (lo = +inf, hi = -inf) that no ray enters.
+struct alignas(64) BvhNode {
+    float llo[3]; int32_t left;
+    float lhi[3]; int32_t right;
+    float rlo[3]; int32_t pad0;
+    float rhi[3]; int32_t pad1;
+};
+
+constexpr int kMaxLeafPrims = 8;   // what the 3-bit count field can hold
+constexpr int kMaxDepth = 60;      // traversal stack capacity bounds the depth
+
+struct BvhResult {
+    std::vector<BvhNode> nodes;       // nodes[0] is the root (always an inner node) unless empty
+    std::vector<uint32_t> order;      // order[k] = input primitive index of reordered slot k
+    int depth = 0;
+};
+
+// boxes: one (already padded) box per primitive.  leaf_size <= kMaxLeafPrims.
+// threads <= 0: pick from hardware_concurrency (capped at 16).
+BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads);
+
+}  // namespace ptrace

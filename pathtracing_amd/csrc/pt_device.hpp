@@ -1,0 +1,512 @@
+// Device code of libptrace (gfx950, wave64).
+//
+// SH = Assets/Scripts/RayTracingShader.compute of the reference.  The shading
+// and intersection arithmetic follows SH operation by operation on top of the
+// intrinsics in include/ptrace_fmath.h (compiled with -ffp-contract=off), so
+// that it produces the same bits as any other implementation written on those
+// intrinsics.  The traversal around it (BVH, work distribution) is free to use
+// fast arithmetic: it only has to be conservative, never exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ptrace.h"
+#include "../../include/ptrace_fmath.h"
+
+namespace ptrace {
+
+typedef pt_f3 f3;
+
+struct SceneDev {
+    const float4 *nodes;       // 4 x float4 per BvhNode
+    const float4 *prims;       // 3 x float4 per primitive record, BVH order
+    const float4 *sphere_mat;  // 4 x float4 per sphere: (pos,r) (albedo,smoothness) (specular,0) (emission,0)
+    const float4 *sky;         // RGBA32F texels, row 0 at v = 0
+    int32_t sky_w, sky_h;
+    int32_t n_nodes, n_prims, n_spheres;
+};
+
+// Primitive record (48 B): a = (v0.xyz, bits(id)), b = (e1.xyz, bits(kind)), c = (e2.xyz, 0)
+// with e1 = v1 - v0, e2 = v2 - v0 in world space (kind 0), or for a sphere
+// a = (centre.xyz, bits(id)), b = (radius, 0, 0, bits(1)).
+// id: 1 + i for sphere i, 1 + n_spheres + k for triangle k in the reference's
+// visiting order; the ground plane is id 0 and a miss is -1.
+
+struct RenderArgs {
+    SceneDev sc;
+    float c2w[16];
+    float ip[16];
+    float seed;
+    int32_t spp, maxb, depth;
+    int32_t W, H;
+    int32_t tx0, ty0, tw, th;     // tile rectangle
+    int32_t tiles_x;              // 8x8 pixel blocks per row of the tile rectangle
+    uint32_t total_items;         // tiles_x * tiles_y * 64
+    float4 *result;
+    float4 *converged;
+    int32_t *hit_ids;
+    int32_t accumulate;
+    uint32_t sample_index;
+    uint32_t *work_counter;
+    unsigned long long *stats;    // [0] rays [1] nodes [2] prims [3] paths
+};
+
+constexpr int kBlock = 256;            // 4 waves
+constexpr int kStackLds = 24;          // traversal stack entries kept in LDS per lane
+constexpr int kStackSpill = 40;        // further entries in private memory (depth bound: bvh.hpp kMaxDepth)
+
+__device__ __forceinline__ float as_f(int32_t i) { return __int_as_float(i); }
+__device__ __forceinline__ int32_t as_i(float f) { return __float_as_int(f); }
+__device__ __forceinline__ f3 xyz(float4 q) { return pt_make3(q.x, q.y, q.z); }
+
+// ------------------------------------------------------------------ traversal
+
+struct Stack {
+    uint32_t *lds;                 // &stack[0][lane]; entry e at lds[e * 64]... see STRIDE
+    int32_t spill[kStackSpill];
+    int sp;
+};
+constexpr int kStackStride = kBlock;  // entries of one lane are kBlock dwords apart (bank = lane % 32)
+
+__device__ __forceinline__ void stack_push(Stack &s, int32_t v)
+{
+    if (s.sp < kStackLds) s.lds[s.sp * kStackStride] = (uint32_t)v;
+    else if (s.sp < kStackLds + kStackSpill) s.spill[s.sp - kStackLds] = v;
+    s.sp++;  // beyond capacity the entry is dropped; the builder's depth bound makes that unreachable
+}
+__device__ __forceinline__ int32_t stack_pop(Stack &s)
+{
+    s.sp--;
+    if (s.sp < kStackLds) return (int32_t)s.lds[s.sp * kStackStride];
+    if (s.sp < kStackLds + kStackSpill) return s.spill[s.sp - kStackLds];
+    return 0;
+}
+
+// One primitive record against the ray; keeps the (t, id)-smallest hit, which is
+// what the reference's strict `t < bestHit.distance` loop in id order keeps
+// (SH:180, SH:245).  Sphere: SH:170-190.  Triangle: SH:192-230 + SH:243-246.
+__device__ __forceinline__ void intersect_prim(const float4 *prims, uint32_t rec, f3 o, f3 d,
+                                               float &tbest, int32_t &idbest, uint32_t &recbest)
+{
+    float4 a = prims[rec * 3 + 0];
+    float4 b = prims[rec * 3 + 1];
+    int32_t id = as_i(a.w);
+    float t;
+    if (as_i(b.w) == 0) {
+        float4 c = prims[rec * 3 + 2];
+        f3 vert0 = xyz(a), edge1 = xyz(b), edge2 = xyz(c);
+        f3 pvec = pt_cross3(d, edge2);
+        float det = pt_dot3(edge1, pvec);
+        if (det < PT_EPSILON) return;
+        float inv_det = 1.0f / det;
+        f3 tvec = pt_sub3(o, vert0);
+        float u = pt_dot3(tvec, pvec) * inv_det;
+        if (u < 0.0f || u > 1.0f) return;
+        f3 qvec = pt_cross3(tvec, edge1);
+        float v = pt_dot3(d, qvec) * inv_det;
+        if (v < 0.0f || u + v > 1.0f) return;
+        t = pt_dot3(edge2, qvec) * inv_det;
+    } else {
+        f3 dd = pt_sub3(o, xyz(a));
+        float radius = b.x;
+        float p1 = -pt_dot3(d, dd);
+        float p2sqr = p1 * p1 - pt_dot3(dd, dd) + radius * radius;
+        if (p2sqr < 0) return;
+        float p2 = pt_sqrt(p2sqr);
+        t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
+    }
+    if (t > 0 && (t < tbest || (t == tbest && id < idbest))) {
+        tbest = t; idbest = id; recbest = rec;
+    }
+}
+
+// Closest hit over spheres and triangles through the BVH.  tbest/idbest come in
+// holding the ground-plane result (or +inf / -1).
+__device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &tbest, int32_t &idbest,
+                                         uint32_t &recbest, Stack &st, uint32_t &n_nodes, uint32_t &n_prims)
+{
+    if (sc.n_nodes == 0) return;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    st.sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        while (node >= 0) {
+            const float4 *q = sc.nodes + (size_t)node * 4;
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            n_nodes++;
+            float l0x = __builtin_fmaf(q0.x, ix, ox), l1x = __builtin_fmaf(q1.x, ix, ox);
+            float l0y = __builtin_fmaf(q0.y, iy, oy), l1y = __builtin_fmaf(q1.y, iy, oy);
+            float l0z = __builtin_fmaf(q0.z, iz, oz), l1z = __builtin_fmaf(q1.z, iz, oz);
+            float r0x = __builtin_fmaf(q2.x, ix, ox), r1x = __builtin_fmaf(q3.x, ix, ox);
+            float r0y = __builtin_fmaf(q2.y, iy, oy), r1y = __builtin_fmaf(q3.y, iy, oy);
+            float r0z = __builtin_fmaf(q2.z, iz, oz), r1z = __builtin_fmaf(q3.z, iz, oz);
+            float ln = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), 0.0f));
+            float lf = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fmaxf(l0z, l1z));
+            float rn = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), 0.0f));
+            float rf = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fmaxf(r0z, r1z));
+            // widened exit distance + non-strict comparisons: never cull a box the exact test would enter
+            bool hl = ln <= lf * 1.000002f && ln <= tbest;
+            bool hr = rn <= rf * 1.000002f && rn <= tbest;
+            int32_t cl = as_i(q0.w), cr = as_i(q1.w);
+            if (hl && hr) {
+                bool left_first = ln <= rn;
+                stack_push(st, left_first ? cr : cl);
+                node = left_first ? cl : cr;
+            } else if (hl) {
+                node = cl;
+            } else if (hr) {
+                node = cr;
+            } else {
+                if (st.sp == 0) return;
+                node = stack_pop(st);
+            }
+        }
+        uint32_t enc = (uint32_t)~node;
+        uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
+        }
+        n_prims += count;
+        if (st.sp == 0) return;
+        node = stack_pop(st);
+    }
+}
+
+// SH:154-168 (distance and id only; the material is filled in by shade()).
+__device__ __forceinline__ void intersect_ground_plane(f3 o, f3 d, float &tbest, int32_t &idbest)
+{
+    float t = -o.y / d.y;
+    if (t > 0 && t < tbest) { tbest = t; idbest = 0; }
+}
+
+// ------------------------------------------------------------------- shading
+
+struct Rng { float seed; float dotp; };  // _Seed and dot(_Pixel, float2(12.9898, 78.233))  SH:47-52
+
+__device__ __forceinline__ float rng_next(Rng &r)  // SH:50-55
+{
+    float result = pt_frac(pt_sin(r.seed / 100.0f * r.dotp) * 43758.5453f);
+    r.seed += 1.0f;
+    return result;
+}
+
+// SH:291-314
+__device__ __forceinline__ f3 sample_hemisphere(Rng &rs, f3 normal, float alpha)
+{
+    float cosTheta = pt_pow(rng_next(rs), 1.0f / (alpha + 1.0f));
+    float sinTheta = pt_sqrt(1.0f - cosTheta * cosTheta);
+    float phi = 2 * PT_PI * rng_next(rs);
+    f3 ts = pt_make3(pt_cos(phi) * sinTheta, pt_sin(phi) * sinTheta, cosTheta);
+    f3 helper = pt_make3(1, 0, 0);
+    if (pt_abs(normal.x) > 0.99f) helper = pt_make3(0, 0, 1);
+    f3 tangent = pt_normalize3(pt_cross3(normal, helper));
+    f3 binormal = pt_normalize3(pt_cross3(normal, tangent));
+    f3 r;
+    r.x = pt_fma(ts.z, normal.x, pt_fma(ts.y, binormal.x, ts.x * tangent.x));
+    r.y = pt_fma(ts.z, normal.y, pt_fma(ts.y, binormal.y, ts.x * tangent.y));
+    r.z = pt_fma(ts.z, normal.z, pt_fma(ts.y, binormal.z, ts.x * tangent.z));
+    return r;
+}
+
+// SH:324-332: bilinear, Repeat wrap, texel centres at (i+0.5)/N, lerp(a,b,t) = a + t*(b-a).
+__device__ __forceinline__ f3 sky_sample(const SceneDev &sc, f3 dir)
+{
+    if (!sc.sky) return pt_make3(0, 0, 0);
+    float theta = pt_acos(dir.y) / -PT_PI;
+    float phi = pt_atan2(dir.x, -dir.z) / -PT_PI * 0.5f;
+    int W = sc.sky_w, H = sc.sky_h;
+    float x = phi * (float)W - 0.5f, y = theta * (float)H - 0.5f;
+    float x0f = pt_floor(x), y0f = pt_floor(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f % W; if (x0 < 0) x0 += W;
+    int y0 = (int)y0f % H; if (y0 < 0) y0 += H;
+    int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
+    float4 c00 = sc.sky[(size_t)y0 * W + x0], c10 = sc.sky[(size_t)y0 * W + x1];
+    float4 c01 = sc.sky[(size_t)y1 * W + x0], c11 = sc.sky[(size_t)y1 * W + x1];
+    f3 a = pt_make3(c00.x + fx * (c10.x - c00.x), c00.y + fx * (c10.y - c00.y), c00.z + fx * (c10.z - c00.z));
+    f3 b = pt_make3(c01.x + fx * (c11.x - c01.x), c01.y + fx * (c11.y - c01.y), c01.z + fx * (c11.z - c01.z));
+    f3 c = pt_make3(a.x + fy * (b.x - a.x), a.y + fy * (b.y - a.y), a.z + fy * (b.z - a.z));
+    return pt_scale3(c, 2.0f);
+}
+
+// Shade (SH:334-373) for the hit (t, id, rec).  Updates origin/direction/energy
+// in place and returns what SH's Shade() returns (emission or sky radiance).
+// `hit_pos` receives bestHit.position ((0,0,0) on a miss, SH:140).
+__device__ __forceinline__ f3 shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f3 &energy,
+                                    float t, int32_t id, uint32_t rec, f3 &hit_pos)
+{
+    if (!(t < PT_INF)) {
+        hit_pos = pt_make3(0, 0, 0);
+        energy = pt_make3(0, 0, 0);
+        return sky_sample(sc, d);
+    }
+    f3 position = pt_along3(o, t, d);
+    hit_pos = position;
+    f3 normal, albedo, specular, emission;
+    float smoothness;
+    if (id == 0) {                                  // SH:162-166
+        normal = pt_make3(0, 1, 0);
+        albedo = pt_make3(0.5f, 0.5f, 0.5f);
+        specular = pt_make3(0.03f, 0.03f, 0.03f);
+        smoothness = 0.2f;
+        emission = pt_make3(0, 0, 0);
+    } else if (id <= sc.n_spheres) {                // SH:184-188
+        const float4 *m = sc.sphere_mat + (size_t)(id - 1) * 4;
+        float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+        normal = pt_normalize3(pt_sub3(position, xyz(m0)));
+        albedo = xyz(m1); smoothness = m1.w;
+        specular = xyz(m2);
+        emission = xyz(m3);
+    } else {                                        // SH:249-253
+        float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
+        normal = pt_normalize3(pt_cross3(xyz(b), xyz(c)));
+        albedo = pt_make3(0, 0, 0);
+        specular = pt_make3(0.65f, 0.65f, 0.65f);
+        smoothness = 0.99f;
+        emission = pt_make3(0, 0, 0);
+    }
+    albedo = pt_make3(pt_min(1.0f - specular.x, albedo.x), pt_min(1.0f - specular.y, albedo.y),
+                      pt_min(1.0f - specular.z, albedo.z));
+    const float third = 1.0f / 3.0f;
+    float specChance = pt_dot3(specular, pt_make3(third, third, third));
+    float diffChance = pt_dot3(albedo, pt_make3(third, third, third));
+    float roulette = rng_next(rs);
+    if (roulette < specChance) {
+        o = pt_along3(position, 0.001f, normal);
+        float alpha = pt_pow(1000.0f, smoothness * smoothness);
+        d = sample_hemisphere(rs, pt_reflect3(d, normal), alpha);
+        float f = (alpha + 2) / (alpha + 1);
+        float k = 1.0f / specChance;
+        float sd = pt_saturate(pt_dot3(normal, d) * f);
+        energy.x *= (k * specular.x) * sd;
+        energy.y *= (k * specular.y) * sd;
+        energy.z *= (k * specular.z) * sd;
+    } else if (diffChance > 0 && roulette < specChance + diffChance) {
+        o = pt_along3(position, 0.001f, normal);
+        d = sample_hemisphere(rs, normal, 1.0f);
+        float k = 1.0f / diffChance;
+        energy.x *= k * albedo.x;
+        energy.y *= k * albedo.y;
+        energy.z *= k * albedo.z;
+    } else {
+        energy = pt_make3(0, 0, 0);
+    }
+    return emission;
+}
+
+// SH:108-120 with uv = id.xy / (W,H) * 2 - 1 (SH:842)
+__device__ __forceinline__ void camera_ray(const RenderArgs &a, int px, int py, f3 &o, f3 &d)
+{
+    float u = (float)px / (float)a.W * 2.0f - 1.0f;
+    float v = (float)py / (float)a.H * 2.0f - 1.0f;
+    o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
+    f3 dir;
+    dir.x = pt_fma(a.ip[4], v, a.ip[0] * u) + a.ip[12];
+    dir.y = pt_fma(a.ip[5], v, a.ip[1] * u) + a.ip[13];
+    dir.z = pt_fma(a.ip[6], v, a.ip[2] * u) + a.ip[14];
+    dir = pt_mul_dir(a.c2w, dir);
+    d = pt_normalize3(dir);
+}
+
+// Converged-image update fused into the final write: AddMat.shader:44-63 with
+// its SrcAlpha/OneMinusSrcAlpha blend (:11), or a running mean, or a sum.
+__device__ __forceinline__ void accumulate_pixel(const RenderArgs &a, size_t p, float4 fresh)
+{
+    if (a.accumulate == PT_ACCUM_NONE || !a.converged) return;
+    float S = (float)a.sample_index;
+    float4 h = a.converged[p];
+    float4 out;
+    if (a.accumulate == PT_ACCUM_MEAN) {
+        float w = 1.0f / (S + 1.0f);
+        out.x = fresh.x * w + h.x * (1.0f - w);
+        out.y = fresh.y * w + h.y * (1.0f - w);
+        out.z = fresh.z * w + h.z * (1.0f - w);
+        out.w = fresh.w * w + h.w * (1.0f - w);
+    } else if (a.accumulate == PT_ACCUM_SUM) {
+        if (a.sample_index == 0) out = fresh;
+        else { out.x = h.x + fresh.x; out.y = h.y + fresh.y; out.z = h.z + fresh.z; out.w = h.w + fresh.w; }
+    } else {
+        float alpha = h.w;
+        float firefly = 0.8f;
+        if (h.x > firefly || h.y > firefly || h.z > firefly) alpha = 0.1f;
+        float t = 1.0f + S * alpha;
+        float A = 1.0f - 1.0f / t;
+        out.x = h.x * A + fresh.x * (1.0f - A);
+        out.y = h.y * A + fresh.y * (1.0f - A);
+        out.z = h.z * A + fresh.z * (1.0f - A);
+        out.w = A * A + fresh.w * (1.0f - A);
+    }
+    a.converged[p] = out;
+}
+
+// --------------------------------------------------------------- path kernel
+//
+// Persistent kernel: the grid is sized to fill the chip once; every lane owns
+// one pixel at a time and pulls the next one from a global counter as soon as
+// its pixel is finished, so lanes whose paths ended early (sky, roulette) are
+// refilled between bounces instead of idling until the longest path of the
+// wave ends.  A pixel's samples are taken in order by one lane because the
+// shader's RNG counter runs on across samples (SH:839: _Seed is never reset).
+//
+// Work item i -> 8x8 pixel block i/64 of the tile rectangle (row-major blocks),
+// pixel i%64 inside it, so the 64 items a fresh wave draws are one block.
+__global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
+{
+    __shared__ uint32_t lds_stack[kStackLds * kStackStride];
+    Stack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.sp = 0;
+    const int lane = threadIdx.x & 63;
+
+    int32_t pix_x = -1, pix_y = 0;   // pix_x < 0: lane has no pixel
+    bool dead = false;                // no work left for this lane
+    int32_t sample = 0, bounce = 0;
+    bool primary_miss = false;
+    Rng rs = {0.0f, 0.0f};
+    f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1), energy = pt_make3(0, 0, 0), result = pt_make3(0, 0, 0);
+    f3 cam_o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
+    float alpha_dist = 0.0f;
+    int32_t primary_id = -1;
+    const float fspp = (float)a.spp;
+    uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_paths = 0;
+
+    for (;;) {
+        // ---- refill idle lanes with new pixels (wave-aggregated counter bump)
+        bool need = pix_x < 0 && !dead;
+        unsigned long long m = __ballot(need);
+        if (m) {
+            int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(a.work_counter, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (need) {
+                uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (item >= a.total_items) {
+                    dead = true;
+                } else {
+                    uint32_t blk = item >> 6, in = item & 63u;
+                    int bx = (int)(blk % (uint32_t)a.tiles_x), by = (int)(blk / (uint32_t)a.tiles_x);
+                    int x = a.tx0 + bx * 8 + (int)(in & 7u), y = a.ty0 + by * 8 + (int)(in >> 3);
+                    if (x < a.tx0 + a.tw && y < a.ty0 + a.th) {
+                        pix_x = x; pix_y = y;
+                        sample = 0; bounce = 0;
+                        rs.seed = a.seed;
+                        rs.dotp = pt_fma((float)y * 2.0f, 78.233f, ((float)x * 2.0f) * 12.9898f);  // SH:831, SH:52
+                        result = pt_make3(0, 0, 0);
+                        energy = pt_make3(1, 1, 1);
+                        camera_ray(a, x, y, o, d);
+                        c_paths++;
+                    }
+                }
+            }
+        }
+        if (__ballot(!dead) == 0ull) break;
+
+        const bool active = pix_x >= 0;
+        if (active) {
+            // ---- Trace (SH:262-285)
+            float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
+            intersect_ground_plane(o, d, t, id);
+            traverse(a.sc, o, d, t, id, rec, st, c_nodes, c_prims);
+            c_rays++;
+
+            if (a.depth == 1) {                                   // SH:799-809
+                size_t p = (size_t)pix_y * a.W + pix_x;
+                float dis = t / 16.0f;
+                a.result[p] = make_float4(dis, dis, dis, dis);
+                if (a.hit_ids) a.hit_ids[p] = id;
+                pix_x = -1;
+            } else {
+                // ---- Shade; energy is read before it is updated (SH:866)
+                f3 e = energy, hit_pos;
+                f3 s = shade(a.sc, rs, o, d, energy, t, id, rec, hit_pos);
+                result.x += e.x * s.x / fspp;
+                result.y += e.y * s.y / fspp;
+                result.z += e.z * s.z / fspp;
+                bool path_done;
+                if (bounce == 0) {
+                    primary_id = id;
+                    primary_miss = !(t < PT_INF);
+                    alpha_dist = pt_length3(pt_sub3(hit_pos, cam_o));  // SH:860, SH:935
+                    // The shader traces once more even when the energy is already zero (SH:867-870).
+                    // After a primary miss that re-trace sees the same ray, draws no random number and
+                    // adds 0 * sky: it is skipped.  Any other zero-energy case is traced, because its
+                    // Shade() advances the RNG counter that later samples of the pixel continue from.
+                    path_done = primary_miss || a.maxb <= 1;
+                } else {
+                    path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
+                }
+                bounce++;
+                if (path_done) {
+                    sample++;
+                    if (sample < a.spp) {                          // next sample of the same pixel, SH:839
+                        bounce = 0;
+                        energy = pt_make3(1, 1, 1);
+                        camera_ray(a, pix_x, pix_y, o, d);
+                        c_paths++;
+                    } else {                                       // SH:933-936
+                        size_t p = (size_t)pix_y * a.W + pix_x;
+                        float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
+                        a.result[p] = fresh;
+                        if (a.hit_ids) a.hit_ids[p] = primary_id;
+                        accumulate_pixel(a, p, fresh);
+                        pix_x = -1;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- counters: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        c_rays += __shfl_down(c_rays, off);
+        c_nodes += __shfl_down(c_nodes, off);
+        c_prims += __shfl_down(c_prims, off);
+        c_paths += __shfl_down(c_paths, off);
+    }
+    if (lane == 0 && a.stats) {
+        atomicAdd(&a.stats[0], (unsigned long long)c_rays);
+        atomicAdd(&a.stats[1], (unsigned long long)c_nodes);
+        atomicAdd(&a.stats[2], (unsigned long long)c_prims);
+        atomicAdd(&a.stats[3], (unsigned long long)c_paths);
+    }
+}
+
+// ------------------------------------------------------- ray-query kernels
+
+// One thread per caller-supplied ray; BVH traversal.
+__global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, const float *od, int n, int32_t *ids, float *ts)
+{
+    __shared__ uint32_t lds_stack[kStackLds * kStackStride];
+    Stack st; st.lds = lds_stack + threadIdx.x; st.sp = 0;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o = pt_make3(od[i * 6 + 0], od[i * 6 + 1], od[i * 6 + 2]);
+    f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);
+    float t = PT_INF; int32_t id = -1; uint32_t rec = 0, cn = 0, cp = 0;
+    intersect_ground_plane(o, d, t, id);
+    traverse(sc, o, d, t, id, rec, st, cn, cp);
+    ids[i] = id; ts[i] = t;
+}
+
+// One thread per ray; every primitive in id order with the shader's strict
+// comparison (SH:262-285).  `by_id` maps id-1 -> record index.
+__global__ __launch_bounds__(kBlock) void trace_rays_brute_kernel(SceneDev sc, const uint32_t *by_id, const float *od, int n,
+                                                                   int32_t *ids, float *ts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o = pt_make3(od[i * 6 + 0], od[i * 6 + 1], od[i * 6 + 2]);
+    f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);
+    float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
+    intersect_ground_plane(o, d, t, id);
+    for (int k = 0; k < sc.n_prims; k++) {
+        // a fresh (+inf, max id) candidate, so that only a strict improvement over `t` is accepted
+        float tc = PT_INF; int32_t ic = 0x7fffffff; uint32_t rc = 0;
+        intersect_prim(sc.prims, by_id[k], o, d, tc, ic, rc);
+        if (tc < t) { t = tc; id = ic; rec = rc; }
+    }
+    ids[i] = id; ts[i] = t;
+}
+
+}  // namespace ptrace

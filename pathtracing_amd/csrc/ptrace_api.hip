@@ -1,0 +1,541 @@
+// libptrace: C ABI (include/ptrace.h) over the HIP kernels in pt_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrace.h"
+#include "bvh.hpp"
+#include "pt_device.hpp"
+
+using namespace ptrace;
+
+struct pt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // host copies of the scene inputs (ComputeBuffer contents)
+    std::vector<PtSphere> spheres;
+    std::vector<PtMeshObject> objects;
+    std::vector<float> vertices;
+    std::vector<int32_t> indices;
+    bool scene_dirty = true;
+
+    // device scene
+    float4 *d_nodes = nullptr, *d_prims = nullptr, *d_sphere_mat = nullptr, *d_sky = nullptr;
+    uint32_t *d_by_id = nullptr;
+    int n_nodes = 0, n_prims = 0, n_spheres = 0, sky_w = 0, sky_h = 0;
+
+    // targets
+    int W = 0, H = 0;
+    float4 *own_result = nullptr, *own_conv = nullptr;
+    int32_t *own_ids = nullptr;
+    float4 *result = nullptr, *conv = nullptr;
+    int32_t *ids = nullptr;
+
+    uint32_t *d_work = nullptr;
+    unsigned long long *d_stats = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool epoch_open = false;  // renders issued since the last pt_get_stats
+    PtStats stats{};
+    int num_cus = 0, blocks_per_cu = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(pt_context *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define PT_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP,              \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+template <class T>
+void free_dev(T *&p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+template <class T>
+int upload(pt_context *ctx, T *&dst, const void *src, size_t bytes)
+{
+    free_dev(dst);
+    if (bytes == 0) return PT_OK;
+    PT_HIP(ctx, hipMalloc((void **)&dst, bytes));
+    PT_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+// Flatten meshes to world space (RayTracingShader.compute:236-240 applied once
+// instead of per ray), box every primitive, build the BVH, upload.
+int rebuild_scene(pt_context *ctx)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    const int nS = (int)ctx->spheres.size();
+    struct Tri { pt_f3 v0, v1, v2; };
+    std::vector<Tri> tris;
+    size_t nt = 0;
+    for (const PtMeshObject &mo : ctx->objects) nt += (size_t)std::max(0, mo.indices_count) / 3;
+    tris.reserve(nt);
+    for (const PtMeshObject &mo : ctx->objects) {
+        const int32_t end = mo.indices_offset + mo.indices_count;
+        for (int32_t i = mo.indices_offset; i + 2 < end; i += 3) {
+            const float *a = &ctx->vertices[3 * (size_t)ctx->indices[i]];
+            const float *b = &ctx->vertices[3 * (size_t)ctx->indices[i + 1]];
+            const float *c = &ctx->vertices[3 * (size_t)ctx->indices[i + 2]];
+            Tri t;
+            t.v0 = pt_mul_point(mo.local_to_world, pt_make3(a[0], a[1], a[2]));
+            t.v1 = pt_mul_point(mo.local_to_world, pt_make3(b[0], b[1], b[2]));
+            t.v2 = pt_mul_point(mo.local_to_world, pt_make3(c[0], c[1], c[2]));
+            tris.push_back(t);
+        }
+    }
+    const size_t nP = (size_t)nS + tris.size();
+    if (nP >= (1u << 28)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^28 primitives");
+
+    std::vector<Aabb> boxes(nP);
+    float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < nS; i++) {
+        const PtSphere &s = ctx->spheres[i];
+        float r = std::fabs(s.radius);
+        for (int k = 0; k < 3; k++) { boxes[i].lo[k] = s.position[k] - r; boxes[i].hi[k] = s.position[k] + r; }
+    }
+    for (size_t j = 0; j < tris.size(); j++) {
+        const float *a = &tris[j].v0.x, *b = &tris[j].v1.x, *c = &tris[j].v2.x;
+        Aabb &bx = boxes[nS + j];
+        for (int k = 0; k < 3; k++) {
+            bx.lo[k] = std::min(a[k], std::min(b[k], c[k]));
+            bx.hi[k] = std::max(a[k], std::max(b[k], c[k]));
+        }
+    }
+    for (size_t i = 0; i < nP; i++)
+        for (int k = 0; k < 3; k++) {
+            if (std::isfinite(boxes[i].lo[k])) slo[k] = std::min(slo[k], boxes[i].lo[k]);
+            if (std::isfinite(boxes[i].hi[k])) shi[k] = std::max(shi[k], boxes[i].hi[k]);
+        }
+    // Pad every box: the intersection tests accept hits a few ulps outside the exact primitive.
+    float diag = 0.0f;
+    if (nP) diag = std::sqrt((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) +
+                             (shi[2] - slo[2]) * (shi[2] - slo[2]));
+    if (!std::isfinite(diag)) diag = 0.0f;
+    const float pad = 1e-5f * diag + 1e-6f;
+    for (size_t i = 0; i < nP; i++)
+        for (int k = 0; k < 3; k++) {
+            float l = boxes[i].lo[k], h = boxes[i].hi[k];
+            float rel = 4e-7f * std::max(std::fabs(l), std::fabs(h));
+            if (!std::isfinite(l) || !std::isfinite(h)) { boxes[i].lo[k] = -INFINITY; boxes[i].hi[k] = INFINITY; continue; }
+            boxes[i].lo[k] = l - pad - rel; boxes[i].hi[k] = h + pad + rel;
+        }
+
+    BvhResult bvh = build_bvh(boxes, 4, 0);
+
+    std::vector<float4> recs(nP * 3);
+    std::vector<uint32_t> by_id(nP);
+    for (size_t slot = 0; slot < nP; slot++) {
+        uint32_t prim = bvh.order[slot];
+        by_id[prim] = (uint32_t)slot;
+        int32_t id = 1 + (int32_t)prim;
+        float idf; std::memcpy(&idf, &id, 4);
+        if ((int)prim < nS) {
+            const PtSphere &s = ctx->spheres[prim];
+            int32_t one = 1; float kind; std::memcpy(&kind, &one, 4);
+            recs[slot * 3 + 0] = make_float4(s.position[0], s.position[1], s.position[2], idf);
+            recs[slot * 3 + 1] = make_float4(s.radius, 0.0f, 0.0f, kind);
+            recs[slot * 3 + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            const Tri &t = tris[prim - nS];
+            pt_f3 e1 = pt_sub3(t.v1, t.v0), e2 = pt_sub3(t.v2, t.v0);
+            recs[slot * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, idf);
+            recs[slot * 3 + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+            recs[slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        }
+    }
+    std::vector<float4> smat((size_t)nS * 4);
+    for (int i = 0; i < nS; i++) {
+        const PtSphere &s = ctx->spheres[i];
+        smat[i * 4 + 0] = make_float4(s.position[0], s.position[1], s.position[2], s.radius);
+        smat[i * 4 + 1] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.smoothness);
+        smat[i * 4 + 2] = make_float4(s.specular[0], s.specular[1], s.specular[2], 0.0f);
+        smat[i * 4 + 3] = make_float4(s.emission[0], s.emission[1], s.emission[2], 0.0f);
+    }
+    int rc;
+    if ((rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;
+    if ((rc = upload(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
+    if ((rc = upload(ctx, ctx->d_by_id, by_id.data(), by_id.size() * sizeof(uint32_t)))) return rc;
+    if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
+    ctx->n_nodes = (int)bvh.nodes.size();
+    ctx->n_prims = (int)nP;
+    ctx->n_spheres = nS;
+    ctx->stats.bvh_nodes = ctx->n_nodes;
+    ctx->stats.bvh_prims = ctx->n_prims;
+    ctx->stats.bvh_depth = bvh.depth;
+    ctx->stats.bvh_build_ms =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->scene_dirty = false;
+    return PT_OK;
+}
+
+SceneDev scene_dev(const pt_context *ctx)
+{
+    SceneDev sc;
+    sc.nodes = ctx->d_nodes; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
+    sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
+    sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres;
+    return sc;
+}
+
+int validate_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, int n_vertices,
+                    const int32_t *indices, int n_indices)
+{
+    for (int o = 0; o < n_objects; o++) {
+        const PtMeshObject &mo = objects[o];
+        if (mo.indices_offset < 0 || mo.indices_count < 0 ||
+            (int64_t)mo.indices_offset + mo.indices_count > n_indices)
+            return fail(ctx, PT_ERR_INVALID, "mesh object " + std::to_string(o) + ": index range outside _Indices");
+    }
+    for (int i = 0; i < n_indices; i++)
+        if (indices[i] < 0 || indices[i] >= n_vertices)
+            return fail(ctx, PT_ERR_INVALID, "index " + std::to_string(i) + " outside _Vertices");
+    return PT_OK;
+}
+
+// Close the statistics epoch: wait for the last render, read its counters.
+int finish_epoch(pt_context *ctx)
+{
+    if (!ctx->epoch_open) return PT_OK;
+    PT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    unsigned long long h[4];
+    PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    ctx->stats.kernel_ms = ms;
+    ctx->stats.rays = h[0]; ctx->stats.nodes_visited = h[1]; ctx->stats.prims_tested = h[2]; ctx->stats.paths = h[3];
+    ctx->epoch_open = false;
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_version(void) { return "libptrace 0.1 (gfx950)"; }
+
+const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_create(int device_ordinal, pt_context **out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, PT_ERR_INVALID, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, PT_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(nullptr, PT_ERR_INVALID, "device ordinal out of range");
+    pt_context *ctx = new (std::nothrow) pt_context();
+    if (!ctx) return fail(nullptr, PT_ERR_NOMEM, "out of host memory");
+    ctx->device = device_ordinal;
+    DeviceGuard g(device_ordinal);
+    auto bail = [&](const char *what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        pt_destroy(ctx);
+        return PT_ERR_HIP;
+    };
+    if (!g.ok) return bail("hipSetDevice", hipErrorInvalidDevice);
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    ctx->stream = ctx->own_stream;
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc((void **)&ctx->d_work, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_stats, 256)) != hipSuccess) return bail("hipMalloc", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->num_cus = prop.multiProcessorCount;
+    int bpc = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->blocks_per_cu = std::max(1, bpc);
+    *out_ctx = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_context *ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    free_dev(ctx->d_nodes); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
+    free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
+    free_dev(ctx->d_work); free_dev(ctx->d_stats);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pt_set_stream(pt_context *ctx, void *hip_stream)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PT_OK;
+}
+
+int pt_set_spheres(pt_context *ctx, const PtSphere *spheres, int count)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (count < 0 || (count > 0 && !spheres)) return fail(ctx, PT_ERR_INVALID, "pt_set_spheres: bad arguments");
+    ctx->spheres.assign(spheres, spheres + count);
+    ctx->scene_dirty = true;
+    return PT_OK;
+}
+
+int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, const float *vertices,
+                  int n_vertices, const int32_t *indices, int n_indices)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (n_objects < 0 || n_vertices < 0 || n_indices < 0 || (n_objects > 0 && !objects) ||
+        (n_vertices > 0 && !vertices) || (n_indices > 0 && !indices))
+        return fail(ctx, PT_ERR_INVALID, "pt_set_meshes: bad arguments");
+    int rc = validate_meshes(ctx, objects, n_objects, n_vertices, indices, n_indices);
+    if (rc) return rc;
+    ctx->objects.assign(objects, objects + n_objects);
+    ctx->vertices.assign(vertices, vertices + (size_t)n_vertices * 3);
+    ctx->indices.assign(indices, indices + n_indices);
+    ctx->scene_dirty = true;
+    return PT_OK;
+}
+
+int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_objects)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (n_objects != (int)ctx->objects.size() || (n_objects > 0 && !objects))
+        return fail(ctx, PT_ERR_INVALID, "pt_update_transforms: object count differs from pt_set_meshes");
+    for (int o = 0; o < n_objects; o++)
+        if (objects[o].indices_offset != ctx->objects[o].indices_offset ||
+            objects[o].indices_count != ctx->objects[o].indices_count)
+            return fail(ctx, PT_ERR_INVALID, "pt_update_transforms: index ranges differ from pt_set_meshes");
+    ctx->objects.assign(objects, objects + n_objects);
+    ctx->scene_dirty = true;
+    return PT_OK;
+}
+
+int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!rgba || width <= 0 || height <= 0) {
+        free_dev(ctx->d_sky); ctx->sky_w = ctx->sky_h = 0;
+        return PT_OK;
+    }
+    int rc = upload(ctx, ctx->d_sky, rgba, (size_t)width * height * sizeof(float4));
+    if (rc) return rc;
+    ctx->sky_w = width; ctx->sky_h = height;
+    return PT_OK;
+}
+
+int pt_resize(pt_context *ctx, int width, int height)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 28)
+        return fail(ctx, PT_ERR_INVALID, "pt_resize: bad size");
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool rebind_r = ctx->result == ctx->own_result, rebind_c = ctx->conv == ctx->own_conv,
+               rebind_i = ctx->ids == ctx->own_ids;
+    free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
+    size_t n = (size_t)width * height;
+    PT_HIP(ctx, hipMalloc((void **)&ctx->own_result, n * sizeof(float4)));
+    PT_HIP(ctx, hipMalloc((void **)&ctx->own_conv, n * sizeof(float4)));
+    PT_HIP(ctx, hipMalloc((void **)&ctx->own_ids, n * sizeof(int32_t)));
+    PT_HIP(ctx, hipMemset(ctx->own_result, 0, n * sizeof(float4)));
+    PT_HIP(ctx, hipMemset(ctx->own_conv, 0, n * sizeof(float4)));
+    PT_HIP(ctx, hipMemset(ctx->own_ids, 0xff, n * sizeof(int32_t)));
+    ctx->W = width; ctx->H = height;
+    if (rebind_r || !ctx->result) ctx->result = ctx->own_result;
+    if (rebind_c || !ctx->conv) ctx->conv = ctx->own_conv;
+    if (rebind_i || !ctx->ids) ctx->ids = ctx->own_ids;
+    return PT_OK;
+}
+
+int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_bind_target before pt_resize");
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    switch (which) {
+    case PT_TARGET_RESULT: ctx->result = device_ptr ? (float4 *)device_ptr : ctx->own_result; break;
+    case PT_TARGET_CONVERGED: ctx->conv = device_ptr ? (float4 *)device_ptr : ctx->own_conv; break;
+    case PT_TARGET_HIT_IDS: ctx->ids = device_ptr ? (int32_t *)device_ptr : ctx->own_ids; break;
+    default: return fail(ctx, PT_ERR_INVALID, "pt_bind_target: unknown target");
+    }
+    return PT_OK;
+}
+
+int pt_render(pt_context *ctx, const PtFrameParams *p)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!p) return fail(ctx, PT_ERR_INVALID, "pt_render: params is NULL");
+    if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_render before pt_resize");
+    if (p->render_mode != 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 1 (Default) is implemented");
+    if (p->max_bounces < 1) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be >= 1");
+    if (p->accumulate < PT_ACCUM_NONE || p->accumulate > PT_ACCUM_ADDMAT) return fail(ctx, PT_ERR_INVALID, "pt_render: bad accumulate mode");
+    int x0 = 0, y0 = 0, tw = ctx->W, th = ctx->H;
+    if (p->tile_w > 0 && p->tile_h > 0) { x0 = p->tile_x0; y0 = p->tile_y0; tw = p->tile_w; th = p->tile_h; }
+    if (x0 < 0 || y0 < 0 || (int64_t)x0 + tw > ctx->W || (int64_t)y0 + th > ctx->H)
+        return fail(ctx, PT_ERR_INVALID, "pt_render: tile outside the image");
+    DeviceGuard g(ctx->device);
+    int rc;
+    if (ctx->scene_dirty) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = rebuild_scene(ctx))) return rc;
+    }
+    if (p->depth != 1 && p->samples_per_pixel <= 0) return PT_OK;  // the shader's sample loop does not run
+
+    RenderArgs a;
+    a.sc = scene_dev(ctx);
+    std::memcpy(a.c2w, p->camera_to_world, sizeof a.c2w);
+    std::memcpy(a.ip, p->camera_inverse_projection, sizeof a.ip);
+    a.seed = p->seed; a.spp = p->samples_per_pixel; a.maxb = p->max_bounces; a.depth = p->depth;
+    a.W = ctx->W; a.H = ctx->H;
+    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th;
+    a.tiles_x = (tw + 7) / 8;
+    const int tiles_y = (th + 7) / 8;
+    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    a.result = ctx->result; a.converged = ctx->conv; a.hit_ids = ctx->ids;
+    a.accumulate = p->accumulate; a.sample_index = p->sample_index;
+    a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
+
+    if (!ctx->epoch_open) {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 256, ctx->stream));
+        PT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        ctx->epoch_open = true;
+    }
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
+    int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
+    int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->blocks_per_cu);
+    hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    return PT_OK;
+}
+
+int pt_sync(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+static int read_back(pt_context *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!dst) return fail(ctx, PT_ERR_INVALID, "output pointer is NULL");
+    if (ctx->W == 0 || !src) return fail(ctx, PT_ERR_INVALID, "read before pt_resize");
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_read_result(pt_context *ctx, float *out)
+{
+    return read_back(ctx, out, ctx ? ctx->result : nullptr, ctx ? (size_t)ctx->W * ctx->H * 16 : 0);
+}
+int pt_read_converged(pt_context *ctx, float *out)
+{
+    return read_back(ctx, out, ctx ? ctx->conv : nullptr, ctx ? (size_t)ctx->W * ctx->H * 16 : 0);
+}
+int pt_read_hit_ids(pt_context *ctx, int32_t *out)
+{
+    return read_back(ctx, out, ctx ? ctx->ids : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+}
+int pt_write_converged(pt_context *ctx, const float *in)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!in || ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_write_converged: bad arguments");
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(ctx->conv, in, (size_t)ctx->W * ctx->H * 16, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+int pt_get_stats(pt_context *ctx, PtStats *out)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_get_stats: out is NULL");
+    DeviceGuard g(ctx->device);
+    int rc = finish_epoch(ctx);
+    if (rc) return rc;
+    *out = ctx->stats;
+    return PT_OK;
+}
+
+int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int brute_force, int32_t *ids_out, float *t_out)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (n_rays < 0 || (n_rays > 0 && (!origins_dirs || !ids_out || !t_out)))
+        return fail(ctx, PT_ERR_INVALID, "pt_trace_rays: bad arguments");
+    if (n_rays == 0) return PT_OK;
+    DeviceGuard g(ctx->device);
+    int rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scene_dirty && (rc = rebuild_scene(ctx))) return rc;
+    float *d_od = nullptr, *d_t = nullptr; int32_t *d_id = nullptr;
+    auto cleanup = [&] { free_dev(d_od); free_dev(d_t); free_dev(d_id); };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_od, (size_t)n_rays * 24)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_t, (size_t)n_rays * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_id, (size_t)n_rays * 4)) != hipSuccess ||
+        (e = hipMemcpy(d_od, origins_dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup();
+        return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
+    }
+    int grid = (n_rays + kBlock - 1) / kBlock;
+    SceneDev sc = scene_dev(ctx);
+    if (brute_force)
+        hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
+    else
+        hipLaunchKernelGGL(trace_rays_bvh_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_od, n_rays, d_id, d_t);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(ctx->stream)) != hipSuccess ||
+        (e = hipMemcpy(ids_out, d_id, (size_t)n_rays * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(t_out, d_t, (size_t)n_rays * 4, hipMemcpyDeviceToHost)) != hipSuccess) {
+        cleanup();
+        return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+/*
+ * ptmaster.h - host side above the libptrace C ABI: a C++ mirror of the
+ * reference's C# host (Assets/Scripts/RayTracingMaster.cs, RayTracingObject.cs)
+ * and the synthetic scenes the benchmarks and tests render.  Everything here is
+ * plain CPU code; only ptm_master_* touches the GPU, and only through
+ * include/ptrace.h.
+ *
+ * The C functions below exist so that the Python test/bench harness can drive
+ * the C++ classes through ctypes.
+ */
+#ifndef PTMASTER_H
+#define PTMASTER_H
+
+#include <stdint.h>
+#include "../../include/ptrace.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scene pieces (CPU only) ------------------------------------------- */
+
+/* SetUpScene (RayTracingMaster.cs:315-369) with a PCG32 stream in place of
+ * UnityEngine.Random (engine-internal, not reproducible).  Returns the number
+ * of spheres written (<= capacity, <= spheres_max). */
+int ptm_sphere_field(int sphere_seed, uint32_t spheres_max, float radius_min, float radius_max,
+                     float placement_radius, PtSphere *out, int capacity);
+
+/* Deterministic lat-long sky (vertical gradient + sun), RGBA32F, w*h texels. */
+void ptm_sky_procedural(int w, int h, float *rgba);
+
+/* Camera.cameraToWorldMatrix and Camera.projectionMatrix.inverse
+ * (RayTracingMaster.cs:489-490) for a camera at `eye` looking at `target`:
+ * OpenGL convention, camera looks down -Z. */
+void ptm_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg,
+                        float aspect, float z_near, float z_far, float cam_to_world[16], float cam_inv_proj[16]);
+
+/* Per-frame _Seed (replaces Random.value, RayTracingMaster.cs:530): frac(0.5 + k * 0.6180339). */
+float ptm_frame_seed(uint32_t k);
+
+/* ---- named synthetic scenes --------------------------------------------
+ * "spheres"   Kuri part-3 field: 100 candidates, radius U(3,8), placement radius 100 (RayTracingMaster.cs:32-34)
+ * "xr"        the repository's TestScene: 200 candidates, radius U(.5,3), placement 20, one rotated cube
+ * "blob70k"   ~70 k-triangle displaced blob + small sphere field
+ * "hall260k"  ~260 k-triangle colonnade hall (columns, arches, bumpy walls, statues)
+ * "city10m"   ~10 M triangles: the hall instanced on a grid through MeshObject matrices
+ * "fixture"   20 spheres + a 320-triangle blob, for brute-force parity tests
+ */
+typedef struct ptm_scene ptm_scene;
+ptm_scene *ptm_scene_create(const char *name);
+void ptm_scene_destroy(ptm_scene *s);
+/* counts[0..3] = spheres, mesh objects, vertices, indices */
+void ptm_scene_counts(const ptm_scene *s, int32_t counts[4]);
+void ptm_scene_copy(const ptm_scene *s, PtSphere *spheres, PtMeshObject *objects, float *vertices, int32_t *indices);
+/* default camera of the scene: eye, target, fov_y_deg */
+void ptm_scene_camera(const ptm_scene *s, float eye[3], float target[3], float *fov_y_deg);
+
+/* Wavefront OBJ (v / f records, polygons fan-triangulated) appended to a scene as one mesh object. */
+int ptm_scene_add_obj(ptm_scene *s, const char *path, const float local_to_world[16]);
+
+/* ---- RayTracingMaster mirror ---------------------------------------------- */
+typedef struct ptm_master ptm_master;
+/* One master = one camera/eye = one libptrace context on `device`. */
+int ptm_master_create(int device, ptm_master **out);
+void ptm_master_destroy(ptm_master *m);
+const char *ptm_master_error(const ptm_master *m);
+pt_context *ptm_master_context(ptm_master *m);
+/* OnEnable + scene upload: spheres and registered meshes of `s`, procedural sky of sky_w x sky_h. */
+int ptm_master_load_scene(ptm_master *m, const ptm_scene *s, int sky_w, int sky_h);
+/* Inspector fields (RayTracingMaster.cs:73-91, 686, 991) */
+int ptm_master_configure(ptm_master *m, int width, int height, int samples_per_pixel, int max_bounces,
+                         int depth, int accumulate, uint32_t sample_frames);
+/* eye_offset: signed offset along the camera's right axis (stereo: -sep/2 left, +sep/2 right). */
+int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov_y_deg, float eye_offset);
+/* Render(): RebuildMeshObjectBuffers, SetShaderParameters, InitRenderTexture, Dispatch (RayTracingMaster.cs:704-747),
+ * then the _currentSample bookkeeping of :885-888.  Asynchronous. */
+int ptm_master_render(ptm_master *m);
+/* The PtFrameParams the next ptm_master_render() would upload (for the oracle to render the same frame). */
+int ptm_master_peek_params(ptm_master *m, PtFrameParams *out);
+/* _currentSample = 0 (RayTracingMaster.cs:145,753) */
+void ptm_master_reset_accumulation(ptm_master *m);
+uint32_t ptm_master_current_sample(const ptm_master *m);
+uint32_t ptm_master_frame_index(const ptm_master *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

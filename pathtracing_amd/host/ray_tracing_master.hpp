@@ -1,0 +1,69 @@
+// C++ mirror of the reference's host component
+// (Assets/Scripts/RayTracingMaster.cs + RayTracingObject.cs), written against
+// the libptrace C ABI only.  Method and field names follow the C# so the two can
+// be read side by side; what Unity's engine supplied (camera matrices,
+// UnityEngine.Random) is supplied by scene.hpp.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/ptrace.h"
+#include "scene.hpp"
+
+namespace ptm {
+
+class RayTracingMaster {
+public:
+    // ---- inspector fields -------------------------------------------------
+    int RenderWidth = 0, RenderHight = 0;        // RayTracingMaster.cs:87-88 (spelling as in the reference)
+    int samplesPerPixel = 1;                      // :85
+    uint32_t sampleFrames = 3;                    // :74
+    bool depth = false;                           // :686
+    int renderMode = 1;                           // RenderMode.Default, :979
+    int maxBounces = 4;                           // hard-coded in the shader, RayTracingShader.compute:867
+    int accumulate = PT_ACCUM_NONE;               // the AddMat pass is dormant in the reference (:804-820)
+
+    // ---- camera (Unity supplies these through Camera) -----------------------
+    float eye[3] = {0, 5, -10}, target[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+    float fieldOfView = 60.0f, nearClip = 0.1f, farClip = 100.0f;  // TestScene.unity:851-853 near/far
+    float eyeOffset = 0.0f;                        // stereo: signed offset along camera right
+
+    explicit RayTracingMaster(int device);
+    ~RayTracingMaster();
+    RayTracingMaster(const RayTracingMaster &) = delete;
+    RayTracingMaster &operator=(const RayTracingMaster &) = delete;
+
+    bool ok() const { return ctx_ != nullptr; }
+    const std::string &error() const { return error_; }
+    pt_context *context() { return ctx_; }
+
+    // OnEnable (RayTracingMaster.cs:139-152): _currentSample = 0; SetUpScene()
+    int OnEnable(const Scene &scene, int sky_w, int sky_h);
+    // RegisterObject / UpdateObject (RayTracingMaster.cs:296-307) act on the scene the master was enabled with.
+    int UpdateObject(int object, const float local_to_world[16]);
+
+    int Render();                                       // :704-747 (+ :885-888)
+    void SetShaderParameters(PtFrameParams &p) const;   // :455-540, :735-738
+    void ResetAccumulation() { currentSample_ = 0; }    // :145, :753
+    uint32_t currentSample() const { return currentSample_; }
+    uint32_t frameIndex() const { return frame_; }
+
+private:
+    int SetUpScene(const Scene &scene);                 // :315-369 (sphere list comes from the Scene)
+    int RebuildMeshObjectBuffers();                     // :371-413
+    int InitRenderTexture();                            // :542-583
+    int check(int rc, const char *what);
+
+    pt_context *ctx_ = nullptr;
+    std::string error_;
+    std::vector<PtMeshObject> meshObjects_;             // _meshObjects  :50
+    std::vector<float> vertices_;                       // _vertices     :51
+    std::vector<int32_t> indices_;                      // _indices      :52
+    bool meshObjectsNeedRebuilding_ = false;            // :48
+    bool geometryUploaded_ = false;
+    int targetW_ = 0, targetH_ = 0;                     // size of _target
+    uint32_t currentSample_ = 0;                        // _currentSample :45
+    uint32_t frame_ = 0;                                // frames dispatched; drives the per-frame _Seed
+};
+
+}  // namespace ptm

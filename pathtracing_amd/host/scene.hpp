@@ -1,0 +1,47 @@
+// C++ side of ptmaster.h: mesh builder, scene container, scene pieces.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/ptrace.h"
+
+namespace ptm {
+
+// Column-major translate * rotate-about-y * uniform scale.
+void matrix_trs(float m[16], float tx, float ty, float tz, float yaw_deg, float scale);
+
+struct MeshBuilder {
+    std::vector<float> vertices;  // xyz
+    std::vector<int> indices;
+    int add_vertex(float x, float y, float z);
+    void add_tri_outward(int a, int b, int c, const float inside[3]);
+    void add_blob(const float c[3], float R, int nu, int nv, float amp, float freq, uint32_t seed);
+    void add_box(const float lo[3], const float hi[3]);
+    void add_column(float cx, float cz, float y0, float y1, float radius, int sides, int rings);
+    void add_arch(float x0, float x1, float y, float cz, float tube, int segs, int sides);
+    void add_wall(float x0, float x1, float y0, float y1, float z, float face, int nx, int ny, float bump, uint32_t seed);
+};
+
+int sphere_field(int sphere_seed, uint32_t spheres_max, float rmin, float rmax, float placement_radius,
+                 std::vector<PtSphere> &out);
+void sky_procedural(int w, int h, float *rgba);
+void camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                    float z_near, float z_far, float c2w[16], float ip[16]);
+float frame_seed(uint32_t k);
+
+// What the reference keeps in its static lists (RayTracingMaster.cs:47-52) plus the sphere list.
+struct Scene {
+    std::string name;
+    std::vector<PtSphere> spheres;
+    std::vector<PtMeshObject> objects;
+    std::vector<float> vertices;
+    std::vector<int32_t> indices;
+    float eye[3] = {0, 5, -10}, target[3] = {0, 0, 0}, fov = 60.0f;
+
+    static Scene *create(const std::string &name);
+    int register_object(const MeshBuilder &mesh, const float local_to_world[16]);  // RegisterObject + rebuild
+    int add_instance(int object, const float local_to_world[16]);                  // same index range, new matrix
+    int add_obj(const std::string &path, const float local_to_world[16]);
+};
+
+}  // namespace ptm

@@ -1,0 +1,469 @@
+// Synthetic scenes and scene pieces (CPU only).  See ptmaster.h.
+#include "scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+
+namespace ptm {
+
+namespace {
+
+// PCG32 (O'Neill), the build's own stand-in for UnityEngine.Random.
+struct Pcg32 {
+    uint64_t state, inc;
+    explicit Pcg32(uint64_t seed, uint64_t seq = 54u)
+    {
+        state = 0u; inc = (seq << 1u) | 1u;
+        next(); state += seed; next();
+    }
+    uint32_t next()
+    {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    // Random.value: uniform in [0,1]
+    float value() { return (float)(next() >> 8) * (1.0f / 16777215.0f); }
+    float range(float a, float b) { return a + value() * (b - a); }
+};
+
+void hsv_to_rgb(float h, float s, float v, float rgb[3])
+{
+    float i = std::floor(h * 6.0f);
+    float f = h * 6.0f - i;
+    float p = v * (1.0f - s), q = v * (1.0f - f * s), t = v * (1.0f - (1.0f - f) * s);
+    switch (((int)i) % 6) {
+    case 0: rgb[0] = v; rgb[1] = t; rgb[2] = p; break;
+    case 1: rgb[0] = q; rgb[1] = v; rgb[2] = p; break;
+    case 2: rgb[0] = p; rgb[1] = v; rgb[2] = t; break;
+    case 3: rgb[0] = p; rgb[1] = q; rgb[2] = v; break;
+    case 4: rgb[0] = t; rgb[1] = p; rgb[2] = v; break;
+    default: rgb[0] = v; rgb[1] = p; rgb[2] = q; break;
+    }
+}
+
+// Cheap smooth value noise in [-1,1] for displacing surfaces.
+float hash3(int x, int y, int z, uint32_t seed)
+{
+    uint32_t h = (uint32_t)x * 0x8da6b343u ^ (uint32_t)y * 0xd8163841u ^ (uint32_t)z * 0xcb1ab31fu ^ seed * 0x9e3779b9u;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return (float)(h & 0xffffff) * (2.0f / 16777215.0f) - 1.0f;
+}
+float noise3(float x, float y, float z, uint32_t seed)
+{
+    int xi = (int)std::floor(x), yi = (int)std::floor(y), zi = (int)std::floor(z);
+    float fx = x - xi, fy = y - yi, fz = z - zi;
+    auto sm = [](float t) { return t * t * (3.0f - 2.0f * t); };
+    float u = sm(fx), v = sm(fy), w = sm(fz);
+    float c[2][2][2];
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int d = 0; d < 2; d++) c[a][b][d] = hash3(xi + a, yi + b, zi + d, seed);
+    auto lerp = [](float a, float b, float t) { return a + t * (b - a); };
+    return lerp(lerp(lerp(c[0][0][0], c[1][0][0], u), lerp(c[0][1][0], c[1][1][0], u), v),
+                lerp(lerp(c[0][0][1], c[1][0][1], u), lerp(c[0][1][1], c[1][1][1], u), v), w);
+}
+
+const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+}  // namespace
+
+// ------------------------------------------------------------------ meshes
+
+void matrix_trs(float m[16], float tx, float ty, float tz, float yaw_deg, float scale)
+{
+    float a = yaw_deg * 3.14159265358979f / 180.0f, c = std::cos(a) * scale, s = std::sin(a) * scale;
+    // column-major: column 0 = (c,0,-s), column 1 = (0,scale,0), column 2 = (s,0,c), column 3 = translation
+    float r[16] = {c, 0, -s, 0, 0, scale, 0, 0, s, 0, c, 0, tx, ty, tz, 1};
+    std::memcpy(m, r, sizeof r);
+}
+
+int MeshBuilder::add_vertex(float x, float y, float z)
+{
+    vertices.push_back(x); vertices.push_back(y); vertices.push_back(z);
+    return (int)(vertices.size() / 3) - 1;
+}
+
+// Adds (a,b,c) wound so that (b-a)x(c-a) points away from `inside`; the shader
+// culls back faces (RayTracingShader.compute:206), so winding decides visibility.
+void MeshBuilder::add_tri_outward(int a, int b, int c, const float inside[3])
+{
+    const float *A = &vertices[3 * a], *B = &vertices[3 * b], *C = &vertices[3 * c];
+    float e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+    float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    float len2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    if (!(len2 > 0.0f)) return;  // degenerate
+    float ctr[3] = {(A[0] + B[0] + C[0]) / 3 - inside[0], (A[1] + B[1] + C[1]) / 3 - inside[1], (A[2] + B[2] + C[2]) / 3 - inside[2]};
+    bool outward = n[0] * ctr[0] + n[1] * ctr[1] + n[2] * ctr[2] >= 0.0f;
+    indices.push_back(a);
+    indices.push_back(outward ? b : c);
+    indices.push_back(outward ? c : b);
+}
+
+// Closed lat-long surface around `c` with radius R * (1 + amp * noise).
+void MeshBuilder::add_blob(const float c[3], float R, int nu, int nv, float amp, float freq, uint32_t seed)
+{
+    int base = (int)(vertices.size() / 3);
+    for (int j = 0; j <= nv; j++) {
+        double th = M_PI * j / nv;
+        for (int i = 0; i < nu; i++) {
+            double ph = 2.0 * M_PI * i / nu;
+            float dx = (float)(std::sin(th) * std::cos(ph)), dy = (float)std::cos(th), dz = (float)(std::sin(th) * std::sin(ph));
+            float r = R * (1.0f + amp * noise3(dx * freq + 11.3f, dy * freq + 5.7f, dz * freq + 2.9f, seed));
+            add_vertex(c[0] + r * dx, c[1] + r * dy, c[2] + r * dz);
+        }
+    }
+    for (int j = 0; j < nv; j++)
+        for (int i = 0; i < nu; i++) {
+            int i1 = (i + 1) % nu;
+            int a = base + j * nu + i, b = base + j * nu + i1, d = base + (j + 1) * nu + i, e = base + (j + 1) * nu + i1;
+            if (j != 0) add_tri_outward(a, b, e, c);
+            if (j != nv - 1) add_tri_outward(a, e, d, c);
+        }
+}
+
+void MeshBuilder::add_box(const float lo[3], const float hi[3])
+{
+    float c[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    int v[8];
+    for (int k = 0; k < 8; k++) v[k] = add_vertex(k & 1 ? hi[0] : lo[0], k & 2 ? hi[1] : lo[1], k & 4 ? hi[2] : lo[2]);
+    const int f[6][4] = {{0, 1, 3, 2}, {4, 5, 7, 6}, {0, 1, 5, 4}, {2, 3, 7, 6}, {0, 2, 6, 4}, {1, 3, 7, 5}};
+    for (auto &q : f) { add_tri_outward(v[q[0]], v[q[1]], v[q[2]], c); add_tri_outward(v[q[0]], v[q[2]], v[q[3]], c); }
+}
+
+// Fluted column: axis along +y from y0 to y1.
+void MeshBuilder::add_column(float cx, float cz, float y0, float y1, float radius, int sides, int rings)
+{
+    int base = (int)(vertices.size() / 3);
+    for (int j = 0; j <= rings; j++) {
+        float t = (float)j / rings, y = y0 + t * (y1 - y0);
+        float taper = 1.0f - 0.15f * t;
+        for (int i = 0; i < sides; i++) {
+            double ph = 2.0 * M_PI * i / sides;
+            float flute = 1.0f + 0.04f * (float)std::cos(ph * 12.0);
+            float r = radius * taper * flute;
+            add_vertex(cx + r * (float)std::cos(ph), y, cz + r * (float)std::sin(ph));
+        }
+    }
+    for (int j = 0; j < rings; j++)
+        for (int i = 0; i < sides; i++) {
+            int i1 = (i + 1) % sides;
+            int a = base + j * sides + i, b = base + j * sides + i1, d = base + (j + 1) * sides + i, e = base + (j + 1) * sides + i1;
+            float y = 0.5f * (vertices[3 * a + 1] + vertices[3 * d + 1]);
+            float in[3] = {cx, y, cz};
+            add_tri_outward(a, b, e, in);
+            add_tri_outward(a, e, d, in);
+        }
+}
+
+// Half torus (an arch) in the plane z = cz spanning x0..x1, springing from height y.
+void MeshBuilder::add_arch(float x0, float x1, float y, float cz, float tube, int segs, int sides)
+{
+    int base = (int)(vertices.size() / 3);
+    float cx = 0.5f * (x0 + x1), R = 0.5f * (x1 - x0);
+    for (int j = 0; j <= segs; j++) {
+        double a = M_PI * j / segs;
+        float ox = cx + R * (float)std::cos(a), oy = y + R * (float)std::sin(a);
+        for (int i = 0; i < sides; i++) {
+            double ph = 2.0 * M_PI * i / sides;
+            float rr = tube * (float)std::cos(ph);
+            add_vertex(ox + rr * (float)std::cos(a), oy + rr * (float)std::sin(a), cz + tube * (float)std::sin(ph));
+        }
+    }
+    for (int j = 0; j < segs; j++) {
+        double am = M_PI * (j + 0.5) / segs;
+        float in[3] = {cx + R * (float)std::cos(am), y + R * (float)std::sin(am), cz};
+        for (int i = 0; i < sides; i++) {
+            int i1 = (i + 1) % sides;
+            int a = base + j * sides + i, b = base + j * sides + i1, d = base + (j + 1) * sides + i, e = base + (j + 1) * sides + i1;
+            add_tri_outward(a, b, e, in);
+            add_tri_outward(a, e, d, in);
+        }
+    }
+}
+
+// Bumpy wall: a height field over the rectangle x0..x1, y0..y1 at z, facing the side `face` (+1 or -1 in z).
+void MeshBuilder::add_wall(float x0, float x1, float y0, float y1, float z, float face, int nx, int ny, float bump, uint32_t seed)
+{
+    int base = (int)(vertices.size() / 3);
+    for (int j = 0; j <= ny; j++)
+        for (int i = 0; i <= nx; i++) {
+            float x = x0 + (x1 - x0) * i / nx, y = y0 + (y1 - y0) * j / ny;
+            float dz = bump * noise3(x * 0.9f, y * 0.9f, 0.5f, seed);
+            add_vertex(x, y, z + face * dz);
+        }
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {
+            int a = base + j * (nx + 1) + i, b = a + 1, d = a + (nx + 1), e = d + 1;
+            float in[3] = {vertices[3 * a], vertices[3 * a + 1], z - face * 10.0f};
+            add_tri_outward(a, b, e, in);
+            add_tri_outward(a, e, d, in);
+        }
+}
+
+// --------------------------------------------------------------- scene pieces
+
+int sphere_field(int sphere_seed, uint32_t spheres_max, float rmin, float rmax, float placement_radius,
+                 std::vector<PtSphere> &out)
+{
+    Pcg32 rng((uint64_t)(uint32_t)sphere_seed);                       // Random.InitState(SphereSeed)  M:317
+    out.clear();
+    for (uint32_t i = 0; i < spheres_max; i++) {                      // M:321
+        PtSphere s; std::memset(&s, 0, sizeof s);
+        s.radius = rmin + rng.value() * (rmax - rmin);                // M:326
+        float px, pz;                                                 // Random.insideUnitCircle  M:327
+        do { px = rng.range(-1.0f, 1.0f); pz = rng.range(-1.0f, 1.0f); } while (px * px + pz * pz > 1.0f);
+        s.position[0] = px * placement_radius; s.position[1] = s.radius; s.position[2] = pz * placement_radius;  // M:328
+        bool skip = false;                                            // M:331-336
+        for (const PtSphere &o : out) {
+            float min_dist = s.radius + o.radius;
+            float dx = s.position[0] - o.position[0], dy = s.position[1] - o.position[1], dz = s.position[2] - o.position[2];
+            if (dx * dx + dy * dy + dz * dz < min_dist * min_dist) { skip = true; break; }
+        }
+        if (skip) continue;
+        float color[3];                                               // Random.ColorHSV()  M:339
+        { float h = rng.value(), sa = rng.value(), v = rng.value(); hsv_to_rgb(h, sa, v, color); }
+        float chance = rng.value();                                   // M:340
+        if (chance < 0.8f) {                                          // M:341-347
+            bool metal = chance < 0.4f;
+            for (int k = 0; k < 3; k++) {
+                s.albedo[k] = metal ? 0.0f : color[k];
+                s.specular[k] = metal ? color[k] : 0.04f;
+            }
+            s.smoothness = rng.value();
+        } else {                                                      // ColorHSV(0,1,0,1,3,8)  M:350-351
+            float h = rng.value(), sa = rng.value(), v = rng.range(3.0f, 8.0f);
+            hsv_to_rgb(h, sa, v, s.emission);
+        }
+        out.push_back(s);                                             // M:355
+    }
+    return (int)out.size();
+}
+
+void sky_procedural(int w, int h, float *rgba)
+{
+    // sun direction (normalised)
+    const double sx = 0.45, sy = 0.55, sz = -0.70;
+    const double sl = std::sqrt(sx * sx + sy * sy + sz * sz);
+    for (int iy = 0; iy < h; iy++) {
+        double v = (iy + 0.5) / h;
+        double dy = std::cos((1.0 - v) * M_PI);          // v = 1 - acos(d.y)/pi  (SH:329, Repeat wrap)
+        double st = std::sqrt(std::max(0.0, 1.0 - dy * dy));
+        for (int ix = 0; ix < w; ix++) {
+            double u = (ix + 0.5) / w;
+            double a = -2.0 * M_PI * u;                   // u = atan2(d.x, -d.z) / -pi * 0.5  (SH:330)
+            double dx = std::sin(a) * st, dz = -std::cos(a) * st;
+            double t = 0.5 * (dy + 1.0);
+            double r, g, b;
+            if (dy >= 0.0) {                              // horizon haze -> zenith blue
+                double k = std::pow(1.0 - dy, 3.0);
+                r = 0.25 + 0.55 * k; g = 0.40 + 0.45 * k; b = 0.75 + 0.20 * k;
+            } else {                                      // below the horizon: dim ground bounce
+                r = 0.18 + 0.1 * t; g = 0.16 + 0.1 * t; b = 0.14 + 0.1 * t;
+            }
+            double cs = (dx * sx + dy * sy + dz * sz) / sl;
+            double ang = std::acos(std::max(-1.0, std::min(1.0, cs)));
+            double sun = 20.0 * std::exp(-(ang * ang) / (2.0 * 0.035 * 0.035)) + 0.6 * std::exp(-(ang * ang) / (2.0 * 0.25 * 0.25));
+            float *p = rgba + 4 * ((size_t)iy * w + ix);
+            p[0] = (float)(r + sun); p[1] = (float)(g + 0.95 * sun); p[2] = (float)(b + 0.8 * sun); p[3] = 1.0f;
+        }
+    }
+}
+
+void camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                    float z_near, float z_far, float c2w[16], float ip[16])
+{
+    auto norm = [](double *v) { double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; };
+    double f[3] = {target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]};
+    norm(f);
+    double u0[3] = {up[0], up[1], up[2]};
+    double r[3] = {f[1] * u0[2] - f[2] * u0[1], f[2] * u0[0] - f[0] * u0[2], f[0] * u0[1] - f[1] * u0[0]};
+    norm(r);
+    double u[3] = {r[1] * f[2] - r[2] * f[1], r[2] * f[0] - r[0] * f[2], r[0] * f[1] - r[1] * f[0]};
+    // camera space: +x right, +y up, -z forward; columns of cameraToWorld are those axes in world space
+    float m[16] = {(float)r[0], (float)r[1], (float)r[2], 0, (float)u[0], (float)u[1], (float)u[2], 0,
+                   (float)-f[0], (float)-f[1], (float)-f[2], 0, eye[0], eye[1], eye[2], 1};
+    std::memcpy(c2w, m, sizeof m);
+    // inverse of the OpenGL perspective matrix
+    double tf = std::tan(fov_y_deg * M_PI / 360.0);
+    float p[16];
+    std::memset(p, 0, sizeof p);
+    p[0] = (float)(aspect * tf);                                     // (0,0)
+    p[5] = (float)tf;                                                // (1,1)
+    p[11] = (float)((z_near - z_far) / (2.0 * z_far * z_near));      // (3,2)
+    p[14] = -1.0f;                                                   // (2,3)
+    p[15] = (float)((z_far + z_near) / (2.0 * z_far * z_near));      // (3,3)
+    std::memcpy(ip, p, sizeof p);
+}
+
+float frame_seed(uint32_t k)
+{
+    double v = 0.5 + (double)k * 0.6180339;
+    return (float)(v - std::floor(v));
+}
+
+// ------------------------------------------------------------------ scenes
+
+int Scene::register_object(const MeshBuilder &mesh, const float local_to_world[16])
+{
+    // RebuildMeshObjectBuffers (RayTracingMaster.cs:387-408): append vertices, append indices offset by
+    // the first vertex, record (matrix, first index, index count).
+    int first_vertex = (int)(vertices.size() / 3);
+    vertices.insert(vertices.end(), mesh.vertices.begin(), mesh.vertices.end());
+    int first_index = (int)indices.size();
+    for (int idx : mesh.indices) indices.push_back(idx + first_vertex);
+    PtMeshObject mo;
+    std::memcpy(mo.local_to_world, local_to_world, sizeof mo.local_to_world);
+    mo.indices_offset = first_index; mo.indices_count = (int)mesh.indices.size();
+    objects.push_back(mo);
+    return (int)objects.size() - 1;
+}
+
+int Scene::add_instance(int object, const float local_to_world[16])
+{
+    PtMeshObject mo = objects[object];
+    std::memcpy(mo.local_to_world, local_to_world, sizeof mo.local_to_world);
+    objects.push_back(mo);
+    return (int)objects.size() - 1;
+}
+
+static void build_hall(MeshBuilder &mb)
+{
+    const float len = 60.0f, half_w = 9.0f, col_h = 9.0f;
+    const int n_cols = 10;
+    for (int side = -1; side <= 1; side += 2) {
+        float z = side * 5.0f;
+        for (int i = 0; i < n_cols; i++) {
+            float x = -len / 2 + (i + 0.5f) * len / n_cols;
+            mb.add_column(x, z, 0.4f, col_h, 0.55f, 72, 32);
+            float lo[3] = {x - 0.8f, 0.0f, z - 0.8f}, hi[3] = {x + 0.8f, 0.4f, z + 0.8f};
+            mb.add_box(lo, hi);
+            float lo2[3] = {x - 0.75f, col_h, z - 0.75f}, hi2[3] = {x + 0.75f, col_h + 0.35f, z + 0.75f};
+            mb.add_box(lo2, hi2);
+            if (i + 1 < n_cols) mb.add_arch(x, x + len / n_cols, col_h + 0.35f, z, 0.3f, 48, 16);
+        }
+        mb.add_wall(-len / 2, len / 2, 0.0f, 14.0f, side * half_w, (float)-side, 160, 40, 0.12f, 77u + (uint32_t)side);
+    }
+    // statues along the nave
+    for (int i = 0; i < 4; i++) {
+        float c[3] = {-len / 2 + (i + 0.5f) * len / 4, 2.2f, 0.0f};
+        mb.add_blob(c, 1.6f, 128, 112, 0.25f, 2.5f, 1000u + (uint32_t)i);
+        float lo[3] = {c[0] - 1.2f, 0.0f, -1.2f}, hi[3] = {c[0] + 1.2f, 0.7f, 1.2f};
+        mb.add_box(lo, hi);
+    }
+    // floor tiles: thin raised slabs, large flat triangles
+    for (int i = 0; i < 30; i++)
+        for (int j = 0; j < 8; j++) {
+            float x = -len / 2 + i * 2.0f, z = -8.0f + j * 2.0f;
+            float lo[3] = {x + 0.03f, -0.02f, z + 0.03f}, hi[3] = {x + 1.97f, 0.02f + 0.01f * ((i + j) & 1), z + 1.97f};
+            mb.add_box(lo, hi);
+        }
+}
+
+Scene *Scene::create(const std::string &name)
+{
+    Scene *s = new Scene();
+    s->name = name;
+    if (name == "spheres") {
+        sphere_field(207407, 100, 3.0f, 8.0f, 100.0f, s->spheres);
+        float e[3] = {0, 22, -125}, t[3] = {0, 4, 0};
+        std::memcpy(s->eye, e, 12); std::memcpy(s->target, t, 12); s->fov = 60.0f;
+    } else if (name == "xr") {
+        sphere_field(207407, 200, 0.5f, 3.0f, 20.0f, s->spheres);
+        MeshBuilder cube;
+        float lo[3] = {-0.5f, -0.5f, -0.5f}, hi[3] = {0.5f, 0.5f, 0.5f};
+        cube.add_box(lo, hi);
+        float m[16]; matrix_trs(m, 0.0f, 3.0f, 6.0f, 33.0f, 2.0f);
+        s->register_object(cube, m);
+        float e[3] = {0, 4.6f, -14}, t[3] = {0, 2.0f, 4};
+        std::memcpy(s->eye, e, 12); std::memcpy(s->target, t, 12); s->fov = 90.0f;
+    } else if (name == "fixture") {
+        sphere_field(12345, 40, 0.6f, 1.6f, 9.0f, s->spheres);
+        if (s->spheres.size() > 20) s->spheres.resize(20);
+        MeshBuilder mb;
+        float c[3] = {0, 0, 0};
+        mb.add_blob(c, 1.5f, 16, 11, 0.3f, 1.7f, 5u);
+        float m[16]; matrix_trs(m, 0.5f, 2.4f, 1.0f, 20.0f, 1.0f);
+        s->register_object(mb, m);
+        float e[3] = {1, 5, -13}, t[3] = {0, 1.5f, 0};
+        std::memcpy(s->eye, e, 12); std::memcpy(s->target, t, 12); s->fov = 60.0f;
+    } else if (name == "blob70k") {
+        sphere_field(424242, 60, 0.8f, 2.5f, 22.0f, s->spheres);
+        // keep the centre clear for the mesh
+        s->spheres.erase(std::remove_if(s->spheres.begin(), s->spheres.end(), [](const PtSphere &sp) {
+            return sp.position[0] * sp.position[0] + sp.position[2] * sp.position[2] < 8.0f * 8.0f; }), s->spheres.end());
+        MeshBuilder mb;
+        float c[3] = {0, 0, 0};
+        mb.add_blob(c, 4.0f, 188, 187, 0.35f, 1.9f, 9u);
+        float m[16]; matrix_trs(m, 0.0f, 4.4f, 0.0f, 15.0f, 1.0f);
+        s->register_object(mb, m);
+        float e[3] = {3, 8, -19}, t[3] = {0, 3.8f, 0};
+        std::memcpy(s->eye, e, 12); std::memcpy(s->target, t, 12); s->fov = 60.0f;
+    } else if (name == "hall260k" || name == "city10m") {
+        MeshBuilder mb;
+        build_hall(mb);
+        if (name == "hall260k") {
+            sphere_field(77, 30, 0.3f, 0.9f, 4.0f, s->spheres);
+            s->register_object(mb, kIdentity);
+            float e[3] = {-27, 4.2f, 1.5f}, t[3] = {10, 3.5f, 0};
+            std::memcpy(s->eye, e, 12); std::memcpy(s->target, t, 12); s->fov = 60.0f;
+        } else {
+            sphere_field(77, 200, 0.5f, 3.0f, 150.0f, s->spheres);
+            Pcg32 rng(99);
+            int first = -1;
+            for (int cell = 0; cell < 38; cell++) {      // 38 x ~262 k triangles
+                int gx = cell % 7, gz = cell / 7;
+                float m[16];
+                matrix_trs(m, (gx - 3) * 75.0f + rng.range(-4, 4), 0.0f, (gz - 2.5f) * 40.0f + rng.range(-4, 4),
+                           rng.range(-20, 20), rng.range(0.9f, 1.1f));
+                if (first < 0) first = s->register_object(mb, m);
+                else s->add_instance(first, m);
+            }
+            float e[3] = {-40, 30, -170}, t[3] = {0, 0, 0};
+            std::memcpy(s->eye, e, 12); std::memcpy(s->target, t, 12); s->fov = 60.0f;
+        }
+    } else {
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+int Scene::add_obj(const std::string &path, const float local_to_world[16])
+{
+    std::ifstream in(path);
+    if (!in) return -1;
+    MeshBuilder mb;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        ls >> tag;
+        if (tag == "v") {
+            float x, y, z;
+            if (ls >> x >> y >> z) mb.add_vertex(x, y, z);
+        } else if (tag == "f") {
+            std::vector<int> poly;
+            std::string tok;
+            int nv = (int)(mb.vertices.size() / 3);
+            while (ls >> tok) {
+                int idx = std::atoi(tok.c_str());   // "i", "i/t", "i/t/n", "i//n"
+                if (idx < 0) idx = nv + idx; else idx -= 1;
+                if (idx < 0 || idx >= nv) return -2;
+                poly.push_back(idx);
+            }
+            for (size_t k = 1; k + 1 < poly.size(); k++) {
+                mb.indices.push_back(poly[0]); mb.indices.push_back((int)poly[k]); mb.indices.push_back((int)poly[k + 1]);
+            }
+        }
+    }
+    if (mb.indices.empty()) return -3;
+    return register_object(mb, local_to_world);
+}
+
+}  // namespace ptm

@@ -1,0 +1,96 @@
+"""Synthetic scenes and frame parameters (CPU side; wraps host/libptmaster.so)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PtFrameParams, PtMeshObject, PtSphere
+
+SCENE_NAMES = ("spheres", "xr", "fixture", "blob70k", "hall260k", "city10m")
+
+
+class Scene:
+    """The reference's scene inputs as flat arrays: spheres (n,14) f32, mesh objects
+    (structured, 72 B each), vertices (n,3) f32, indices int32 - the exact buffer
+    layouts of RayTracingMaster.cs:93-108 - plus a default camera."""
+
+    def __init__(self, name):
+        lib = _ffi.ptmaster()
+        self.name = name
+        self._h = lib.ptm_scene_create(name.encode())
+        if not self._h:
+            raise ValueError(f"unknown scene {name!r}; known: {SCENE_NAMES}")
+        self._refresh()
+
+    def _refresh(self):
+        lib = _ffi.ptmaster()
+        counts = (C.c_int32 * 4)()
+        lib.ptm_scene_counts(self._h, counts)
+        ns, no, nv, ni = counts
+        self.spheres = np.zeros((ns, 14), np.float32)
+        self.objects = np.zeros(no, dtype=np.dtype([("m", np.float32, 16), ("offset", np.int32), ("count", np.int32)]))
+        self.vertices = np.zeros((nv, 3), np.float32)
+        self.indices = np.zeros(ni, np.int32)
+        lib.ptm_scene_copy(self._h, self.spheres.ctypes.data, self.objects.ctypes.data,
+                           self.vertices.ctypes.data, self.indices.ctypes.data)
+        eye = (C.c_float * 3)(); tgt = (C.c_float * 3)(); fov = C.c_float()
+        lib.ptm_scene_camera(self._h, eye, tgt, C.byref(fov))
+        self.eye = np.array(eye, np.float32); self.target = np.array(tgt, np.float32); self.fov = float(fov.value)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def n_triangles(self):
+        return int(self.objects["count"].sum() // 3) if len(self.objects) else 0
+
+    def add_obj(self, path, local_to_world=None):
+        m = np.eye(4, dtype=np.float32).T.reshape(16) if local_to_world is None else np.asarray(local_to_world, np.float32)
+        rc = _ffi.ptmaster().ptm_scene_add_obj(self._h, str(path).encode(), m.ctypes.data)
+        if rc < 0:
+            raise ValueError(f"cannot load OBJ {path}: code {rc}")
+        self._refresh()
+        return rc
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.ptmaster().ptm_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def procedural_sky(w=256, h=128):
+    sky = np.zeros((h, w, 4), np.float32)
+    _ffi.ptmaster().ptm_sky_procedural(w, h, sky.ctypes.data)
+    return sky
+
+
+def frame_seed(k):
+    return float(_ffi.ptmaster().ptm_frame_seed(int(k)))
+
+
+def camera_matrices(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1, z_far=100.0):
+    e = np.asarray(eye, np.float32); t = np.asarray(target, np.float32); u = np.asarray(up, np.float32)
+    c2w = np.zeros(16, np.float32); ip = np.zeros(16, np.float32)
+    _ffi.ptmaster().ptm_camera_look_at(e.ctypes.data, t.ctypes.data, u.ctypes.data, fov_deg, aspect, z_near, z_far,
+                                       c2w.ctypes.data, ip.ctypes.data)
+    return c2w, ip
+
+
+def make_params(scene, width, height, *, seed=0.5, spp=1, max_bounces=8, depth=0, accumulate=0, sample_index=0,
+                tile=None, eye=None, target=None, fov=None):
+    """PtFrameParams for `scene`'s default (or the given) camera."""
+    c2w, ip = camera_matrices(scene.eye if eye is None else eye, scene.target if target is None else target,
+                              scene.fov if fov is None else fov, width / height)
+    p = PtFrameParams()
+    p.camera_to_world[:] = c2w.tolist()
+    p.camera_inverse_projection[:] = ip.tolist()
+    p.seed = seed; p.samples_per_pixel = spp; p.max_bounces = max_bounces; p.depth = depth
+    p.render_mode = 1; p.sample_index = sample_index; p.accumulate = accumulate
+    if tile is not None:
+        p.tile_x0, p.tile_y0, p.tile_w, p.tile_h = tile
+    p.directional_light[1] = -1.0; p.directional_light[3] = 1.0
+    return p

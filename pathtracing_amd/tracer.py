@@ -1,0 +1,124 @@
+"""PathTracer: a libptrace context (one per GPU / eye), driven through the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PtFrameParams, PtStats
+
+
+class PtraceError(RuntimeError):
+    pass
+
+
+class PathTracer:
+    def __init__(self, device=0):
+        self._lib = _ffi.ptrace()
+        self._ctx = C.c_void_p()
+        rc = self._lib.pt_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.pt_last_error(None).decode()
+            self._ctx = None
+            raise PtraceError(f"pt_create({device}) failed ({rc}): {msg}")
+        self.width = self.height = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PtraceError(f"{what} failed ({rc}): {self._lib.pt_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- scene ------------------------------------------------------------
+    def set_spheres(self, spheres):
+        s = np.ascontiguousarray(spheres, np.float32).reshape(-1, 14)
+        self._check(self._lib.pt_set_spheres(self._ctx, s.ctypes.data if len(s) else None, len(s)), "pt_set_spheres")
+
+    def set_meshes(self, objects, vertices, indices):
+        o = np.ascontiguousarray(objects)
+        assert o.dtype.itemsize == 72 or len(o) == 0
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, np.int32)
+        self._check(self._lib.pt_set_meshes(self._ctx, o.ctypes.data if len(o) else None, len(o),
+                                            v.ctypes.data if len(v) else None, len(v),
+                                            i.ctypes.data if len(i) else None, len(i)), "pt_set_meshes")
+
+    def update_transforms(self, objects):
+        o = np.ascontiguousarray(objects)
+        self._check(self._lib.pt_update_transforms(self._ctx, o.ctypes.data if len(o) else None, len(o)), "pt_update_transforms")
+
+    def set_sky(self, sky):
+        if sky is None:
+            self._check(self._lib.pt_set_sky(self._ctx, None, 0, 0), "pt_set_sky")
+            return
+        s = np.ascontiguousarray(sky, np.float32)
+        h, w = s.shape[:2]
+        self._check(self._lib.pt_set_sky(self._ctx, s.ctypes.data, w, h), "pt_set_sky")
+
+    def load_scene(self, scene, sky=None):
+        self.set_spheres(scene.spheres)
+        self.set_meshes(scene.objects, scene.vertices, scene.indices)
+        self.set_sky(sky)
+
+    # ---- targets / render ---------------------------------------------------
+    def resize(self, width, height):
+        self._check(self._lib.pt_resize(self._ctx, int(width), int(height)), "pt_resize")
+        self.width, self.height = int(width), int(height)
+
+    def bind_target(self, which, device_ptr):
+        self._check(self._lib.pt_bind_target(self._ctx, int(which), C.c_void_p(device_ptr)), "pt_bind_target")
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.pt_set_stream(self._ctx, C.c_void_p(stream_ptr)), "pt_set_stream")
+
+    def render(self, params):
+        self._check(self._lib.pt_render(self._ctx, C.byref(params)), "pt_render")
+
+    def sync(self):
+        self._check(self._lib.pt_sync(self._ctx), "pt_sync")
+
+    def read_result(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.pt_read_result(self._ctx, out.ctypes.data), "pt_read_result")
+        return out
+
+    def read_converged(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.pt_read_converged(self._ctx, out.ctypes.data), "pt_read_converged")
+        return out
+
+    def write_converged(self, img):
+        a = np.ascontiguousarray(img, np.float32)
+        assert a.shape == (self.height, self.width, 4)
+        self._check(self._lib.pt_write_converged(self._ctx, a.ctypes.data), "pt_write_converged")
+
+    def read_hit_ids(self):
+        out = np.empty((self.height, self.width), np.int32)
+        self._check(self._lib.pt_read_hit_ids(self._ctx, out.ctypes.data), "pt_read_hit_ids")
+        return out
+
+    def stats(self):
+        st = PtStats()
+        self._check(self._lib.pt_get_stats(self._ctx, C.byref(st)), "pt_get_stats")
+        return {k: getattr(st, k) for k, _ in PtStats._fields_}
+
+    def trace_rays(self, origins_dirs, brute_force=False):
+        od = np.ascontiguousarray(origins_dirs, np.float32).reshape(-1, 6)
+        ids = np.empty(len(od), np.int32); ts = np.empty(len(od), np.float32)
+        self._check(self._lib.pt_trace_rays(self._ctx, od.ctypes.data, len(od), int(bool(brute_force)),
+                                            ids.ctypes.data, ts.ctypes.data), "pt_trace_rays")
+        return ids, ts

@@ -1,0 +1,146 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same inputs.  fp32 images are compared BIT-EXACT (tolerance 0): both sides are
+written on the intrinsics of include/ptrace_fmath.h with contraction off."""
+import numpy as np
+import pytest
+
+import pathtracing_amd as pa
+from oracle import pt_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _assert_same_image(gpu, cpu, what):
+    neq = _bits(gpu) != _bits(cpu)
+    # NaN == NaN bitwise here, so any difference is a real one
+    assert not neq.any(), f"{what}: {int(neq.sum())} of {neq.size} floats differ; first at {np.argwhere(neq)[0]}: " \
+                          f"gpu={gpu[tuple(np.argwhere(neq)[0])]} cpu={cpu[tuple(np.argwhere(neq)[0])]}"
+
+
+@pytest.fixture(scope="module")
+def fixture_scene(tracer, sky_small):
+    s = pa.Scene("fixture")
+    tracer.load_scene(s, sky_small)
+    return s, po.Oracle.from_scene(s, sky_small, accel=False)
+
+
+@pytest.mark.parametrize("spp,maxb", [(1, 4), (1, 8), (4, 8), (16, 4)])
+def test_fixture_image_bit_exact(tracer, fixture_scene, spp, maxb):
+    s, orc = fixture_scene
+    W, H = 64, 36
+    tracer.resize(W, H)
+    p = pa.make_params(s, W, H, seed=0.5, spp=spp, max_bounces=maxb)
+    tracer.render(p)
+    g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+    c, cid, cst = orc.render(p, W, H, threads=4)
+    assert (gid == cid).all(), f"{int((gid != cid).sum())} primary hit ids differ"
+    _assert_same_image(g, c, f"spp={spp} maxb={maxb}")
+    assert st["rays"] == cst["rays"] and st["paths"] == cst["paths"]
+    assert np.isfinite(g).all() and g[..., :3].max() > 0
+
+
+def test_depth_mode(tracer, fixture_scene):
+    s, orc = fixture_scene
+    W, H = 64, 36
+    tracer.resize(W, H)
+    p = pa.make_params(s, W, H, depth=1)
+    tracer.render(p)
+    g = tracer.read_result()
+    c, cid, _ = orc.render(p, W, H)
+    _assert_same_image(g, c, "depth")
+    assert np.isinf(g).any() and (tracer.read_hit_ids() == cid).all()
+
+
+def test_odd_size_and_tile(tracer, fixture_scene):
+    s, orc = fixture_scene
+    W, H = 37, 23          # not multiples of 8 (the reference's 1080 is not a multiple of 32 either)
+    tracer.resize(W, H)
+    p = pa.make_params(s, W, H, spp=2, max_bounces=8, seed=0.25)
+    tracer.render(p)
+    g = tracer.read_result()
+    c, _, _ = orc.render(p, W, H)
+    _assert_same_image(g, c, "odd size")
+    # a tile leaves every other pixel untouched
+    tracer.resize(W, H)
+    pt = pa.make_params(s, W, H, spp=2, max_bounces=8, seed=0.25, tile=(5, 3, 13, 9))
+    tracer.render(pt)
+    gt = tracer.read_result()
+    _assert_same_image(gt[3:12, 5:18], c[3:12, 5:18], "tile")
+    mask = np.ones((H, W), bool); mask[3:12, 5:18] = False
+    assert (gt[mask] == 0).all()
+
+
+@pytest.mark.parametrize("mode", [pa.PT_ACCUM_MEAN, pa.PT_ACCUM_SUM, pa.PT_ACCUM_ADDMAT])
+def test_accumulation_modes(tracer, fixture_scene, mode):
+    s, orc = fixture_scene
+    W, H = 48, 27
+    tracer.resize(W, H)
+    conv = np.zeros((H, W, 4), np.float32)
+    for k in range(4):
+        p = pa.make_params(s, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, accumulate=mode, sample_index=k)
+        tracer.render(p)
+        fresh, _, _ = orc.render(p, W, H)
+        conv = po.accumulate(mode, k, fresh, conv)
+    _assert_same_image(tracer.read_converged(), conv, f"accumulate mode {mode}")
+
+
+def test_empty_scene_and_no_sky(tracer):
+    W, H = 32, 16
+    e = np.zeros((0, 14), np.float32)
+    tracer.set_spheres(e); tracer.set_meshes(np.zeros(0, np.dtype([("m", np.float32, 16), ("o", np.int32), ("c", np.int32)])),
+                                             np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+    tracer.set_sky(None)
+    tracer.resize(W, H)
+    s = pa.Scene("fixture")
+    p = pa.make_params(s, W, H, spp=1, max_bounces=4)
+    tracer.render(p)
+    g = tracer.read_result(); ids = tracer.read_hit_ids()
+    orc = po.Oracle(e, np.zeros(0, np.dtype([("m", np.float32, 16), ("o", np.int32), ("c", np.int32)])),
+                    np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+    c, cid, _ = orc.render(p, W, H)
+    _assert_same_image(g, c, "empty scene")
+    assert (ids == cid).all() and set(np.unique(ids)) <= {-1, 0}
+
+
+def test_bvh_equals_exhaustive_loop_on_device(tracer, sky_small):
+    """The acceleration structure returns the hit of the reference's loop over every primitive."""
+    s = pa.Scene("blob70k")
+    tracer.load_scene(s, sky_small)
+    rng = np.random.default_rng(7)
+    n = 20000
+    o = rng.uniform(-25, 25, (n, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.1, 20, n)
+    tgt = rng.uniform(-5, 5, (n, 3)).astype(np.float32); tgt[:, 1] += 4
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    od = np.concatenate([o, d.astype(np.float32)], axis=1)
+    ib, tb = tracer.trace_rays(od, brute_force=False)
+    ie, te = tracer.trace_rays(od, brute_force=True)
+    assert (ib == ie).all(), f"{int((ib != ie).sum())} of {n} hit ids differ"
+    assert (_bits(tb) == _bits(te)).all()
+    assert (ib > 0).mean() > 0.2
+    # and the oracle's exhaustive loop agrees on a subset
+    orc = po.Oracle.from_scene(s, accel=False)
+    io, to = orc.trace_rays(od[:300])
+    assert (io == ib[:300]).all() and (_bits(to) == _bits(tb[:300])).all()
+
+
+def test_mesh_scene_against_oracle_bvh(tracer, sky_small):
+    """~70 k triangles at 256x144: too big for the exhaustive oracle, so the oracle's own BVH
+    (proved equal to the exhaustive loop in the CPU tests) is the checker."""
+    s = pa.Scene("blob70k")
+    tracer.load_scene(s, sky_small)
+    W, H = 256, 144
+    tracer.resize(W, H)
+    p = pa.make_params(s, W, H, seed=0.5, spp=2, max_bounces=8)
+    tracer.render(p)
+    g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+    orc = po.Oracle.from_scene(s, sky_small, accel=True)
+    c, cid, cst = orc.render(p, W, H, threads=8)
+    mism = (gid != cid).mean()
+    assert mism == 0, f"primary hit-id mismatch rate {mism}"
+    _assert_same_image(g, c, "blob70k")
+    assert st["rays"] == cst["rays"]
+    assert (gid > len(s.spheres)).mean() > 0.05   # the mesh is actually in view
