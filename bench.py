@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one frame of the workload: a 1920x1080
+image of the ~260 k-triangle hall scene, 8 bounces, --spp samples per pixel per
+GPU.  With N GPUs every rank renders its own --spp samples of the same image
+(different sample indices / seeds; the scene is replicated) and the per-rank
+frames are sum-reduced to rank 0 over RCCL each step: weak scaling, the
+BASELINE config "1024 spp sharded across 8 GPUs with RCCL reduce" cut into steps.
+
+Prints ONE JSON line (rank 0): metric Mrays/s = Trace() calls executed by the
+kernels (counted on the device) per second of wall time, summed over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NODE_BYTES = 64      # one BVH node: both children's boxes + links (pathtracing_amd/csrc/bvh.hpp)
+PRIM_BYTES = 48      # one primitive record: v0, e1, e2 (+ id, kind)
+PIXEL_BYTES = 16     # RGBA32F result write per pixel
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="hall260k")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per GPU per step")
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--stereo", action="store_true", help="also time the 1080p stereo frame (2 eyes, 1 spp, 4 bounces)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, sky, args):
+    """The CPU oracle (a port of the reference shader) on a bounded sample of the same workload."""
+    from oracle import pt_oracle as po
+    import pathtracing_amd as pa
+    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    W, H = args.width, args.height
+    tile = (W // 2 - W // 8, H // 2 - H // 8, W // 4, H // 4)
+    spp = 2
+    orc = po.Oracle.from_scene(scene, sky, accel=True)
+    p = pa.make_params(scene, W, H, seed=pa.frame_seed(0), spp=spp, max_bounces=args.bounces, tile=tile)
+    t0 = time.perf_counter()
+    _, _, st = orc.render(p, W, H, threads=threads)
+    dt = time.perf_counter() - t0
+    out = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"central {tile[2]}x{tile[3]} tile of the {W}x{H} frame, {spp} spp, {args.bounces} bounces, "
+                     f"oracle with its own median-split BVH, {st['rays']} rays in {dt:.1f} s"}
+    # the reference's own algorithm has no acceleration structure: time the exhaustive loop on a much smaller sample
+    tile2 = (W // 2 - 16, H // 2 - 9, 32, 18)
+    orc2 = po.Oracle.from_scene(scene, sky, accel=False)
+    p2 = pa.make_params(scene, W, H, seed=pa.frame_seed(0), spp=1, max_bounces=args.bounces, tile=tile2)
+    t0 = time.perf_counter()
+    _, _, st2 = orc2.render(p2, W, H, threads=threads)
+    dt2 = time.perf_counter() - t0
+    out["exhaustive_loop"] = {"value": st2["rays"] / dt2 / 1e6, "unit": "Mrays/s",
+                              "sample": f"{tile2[2]}x{tile2[3]} tile, 1 spp, every triangle tested per ray as the "
+                                        f"reference does, {st2['rays']} rays in {dt2:.1f} s"}
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import pathtracing_amd as pa
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    scene = pa.Scene(args.scene)
+    sky = pa.procedural_sky(2048, 1024)
+    tr = pa.PathTracer(local_rank)
+    tr.load_scene(scene, sky)
+    tr.resize(W, H)
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # this rank's fresh frame ("Result")
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # rank 0: sum over steps and ranks
+    tr.bind_target(pa.PT_TARGET_RESULT, frame.data_ptr())
+    tr.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step(k):
+        # sample index of this rank in step k: k*world + rank  -> its own seed
+        p = pa.make_params(scene, W, H, seed=pa.frame_seed(k * world + rank), spp=args.spp, max_bounces=args.bounces)
+        tr.render(p)
+        if dist is not None:
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            accum.add_(frame)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    tr.stats()                      # close the statistics epoch of the warm-up
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    st = tr.stats()
+
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([st["rays"], st["nodes_visited"], st["prims_tested"], st["paths"]], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(t_all.item())
+    rays, nodes, prims, paths = [float(x) for x in counts.tolist()]
+
+    if rank == 0:
+        img = (accum / float(args.steps * world * 1.0)).cpu().numpy()   # every frame is already a mean over --spp samples
+        mrays = rays / dt / 1e6
+        # dominant kernel = path_kernel; its launches are back to back on the stream, kernel_ms spans them
+        launches = args.steps
+        kernel_ms = st["kernel_ms"] / launches
+        r_rank = st["rays"]
+        alg_bytes = (st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES) / launches + W * H * PIXEL_BYTES
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (all bounces)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} ({scene.n_triangles} triangles + {len(scene.spheres)} spheres + ground plane, "
+                                   f"2048x1024 procedural sky) {W}x{H}, {args.bounces} bounces, {args.spp} spp per GPU per step",
+                       "parallelism": f"spp-sharded x{world}, scene replicated, RCCL sum-reduce of the frame per step"
+                       if world > 1 else "single GPU",
+                       "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "path_kernel", "kernel_ms": kernel_ms,
+                         "bytes_per_ray": (st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES) / max(1, r_rank),
+                         "nodes_per_ray": st["nodes_visited"] / max(1, r_rank),
+                         "prims_per_ray": st["prims_tested"] / max(1, r_rank),
+                         "kernel_mrays_per_s": r_rank / launches / (kernel_ms * 1e-3) / 1e6},
+            "image_mean_rgb": [float(x) for x in img[..., :3].reshape(-1, 3).mean(axis=0)],
+            "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
+        }
+        if args.stereo and world == 1:
+            out["stereo_1080p"] = stereo_frame_time(pa, torch)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, sky, args)
+        print(json.dumps(out), flush=True)
+    tr.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def stereo_frame_time(pa, torch, frames=30):
+    """ms per stereo frame: two 1920x1080 eyes, 1 spp, 4 bounces (the shader's own count), running-mean
+    accumulation, one GPU, on the repository's default scene."""
+    scene = pa.Scene("xr")
+    sky = pa.procedural_sky(2048, 1024)
+    eyes = []
+    for _ in range(2):
+        t = pa.PathTracer(torch.cuda.current_device())
+        t.load_scene(scene, sky); t.resize(1920, 1080)
+        eyes.append(t)
+    sep = 0.022
+    def frame(k):
+        for e, t in enumerate(eyes):
+            off = np.array([(-0.5 + e) * sep, 0, 0], np.float32)
+            p = pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(k), spp=1, max_bounces=4,
+                               accumulate=pa.PT_ACCUM_MEAN, sample_index=min(k, 10),
+                               eye=scene.eye + off, target=scene.target + off, fov=90.0)
+            t.render(p)
+    for k in range(3):
+        frame(k)
+    for t in eyes:
+        t.sync()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        frame(3 + k)
+    for t in eyes:
+        t.sync()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    for t in eyes:
+        t.close()
+    return {"ms_per_frame": ms, "frames": frames, "config": "xr scene, 2 x 1920x1080, 1 spp, 4 bounces, mean accumulation, 1 GPU"}
+
+
+if __name__ == "__main__":
+    main()

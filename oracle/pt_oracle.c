@@ -39,7 +39,7 @@ struct PtoPrepared {
 
 typedef struct RngState { float seed; float px, py; } RngState;  /* _Seed, _Pixel  SH:47-48 */
 
-typedef struct Counters { uint64_t trace_calls, rays, paths, prims; } Counters;
+typedef struct Counters { uint64_t trace_calls, rays, paths, prims; float *log; int log_cap, log_n; } Counters;
 
 /* ------------------------------------------------------------- utilities */
 
@@ -175,7 +175,12 @@ static int box_hit(const ONode *n, const Ray *ray, f3 inv, float best)
 static void trace_bvh(const PtoPrepared *p, const Ray *ray, RayHit *best, Counters *cn)
 {
     if (p->n_nodes == 0) return;
-    f3 inv = pt_make3(1.0f / ray->direction.x, 1.0f / ray->direction.y, 1.0f / ray->direction.z);
+    /* |d| clamped away from zero so that no slab distance is 0 * inf */
+    f3 dd = ray->direction;
+    if (fabsf(dd.x) < 1e-18f) dd.x = copysignf(1e-18f, dd.x);
+    if (fabsf(dd.y) < 1e-18f) dd.y = copysignf(1e-18f, dd.y);
+    if (fabsf(dd.z) < 1e-18f) dd.z = copysignf(1e-18f, dd.z);
+    f3 inv = pt_make3(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z);
     int32_t stack[128]; int sp = 0;
     stack[sp++] = 0;
     while (sp) {
@@ -208,6 +213,19 @@ static RayHit trace(const PtoPrepared *p, const Ray *ray, Counters *cn)
         intersect_tri(ray, &best, &p->tris[k], 1 + p->n_spheres + k, 0);
     cn->prims += (uint64_t)p->n_spheres + (uint64_t)p->n_tris;
     return best;
+}
+
+/* Trace() plus an optional log of (origin, direction, id, distance) per call, for tests. */
+static RayHit trace_logged(const PtoPrepared *p, const Ray *ray, Counters *cn)
+{
+    RayHit h = trace(p, ray, cn);
+    if (cn->log && cn->log_n < cn->log_cap) {
+        float *e = cn->log + 8 * cn->log_n++;
+        e[0] = ray->origin.x; e[1] = ray->origin.y; e[2] = ray->origin.z;
+        e[3] = ray->direction.x; e[4] = ray->direction.y; e[5] = ray->direction.z;
+        e[6] = (float)h.id; e[7] = h.distance;
+    }
+    return h;
 }
 
 /* ---------------------------------------------------------------- sampling */
@@ -339,7 +357,7 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
     for (int j = 1; j < spp + 1; j++) {            /* SH:839 */
         Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
         cn->paths++;
-        RayHit hit = trace(p, &ray, cn);           /* SH:859 */
+        RayHit hit = trace_logged(p, &ray, cn);    /* SH:859 */
         cn->rays++;
         f3 hitPos = hit.position;                  /* SH:860; (0,0,0) on a miss */
         if (hit_id) *hit_id = hit.id;
@@ -350,7 +368,7 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
             result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
         }
         for (int i = 1; i < maxb; i++) {           /* SH:867 (4 in the shader) */
-            hit = trace(p, &ray, cn);
+            hit = trace_logged(p, &ray, cn);
             if (!(i == 1 && primary_miss)) cn->rays++;
             f3 e = ray.energy;
             f3 s = shade(p, &rs, &ray, hit);
@@ -374,7 +392,7 @@ int pto_render(const PtoPrepared *p, const PtFrameParams *prm, int W, int H,
     uint64_t a = 0, b = 0, c = 0, d = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a, b, c, d)
     for (int y = y0; y < y0 + th; y++) {
-        Counters cn = {0, 0, 0, 0};
+        Counters cn = {0, 0, 0, 0, NULL, 0, 0};
         for (int x = x0; x < x0 + tw; x++) {
             size_t px = (size_t)y * W + x;
             cs_main(p, prm, W, H, x, y, result + 4 * px, hit_ids ? hit_ids + px : NULL, &cn);
@@ -543,7 +561,7 @@ void pto_camera_ray(const float *c2w, const float *ip, int idx, int idy, int W, 
 
 void pto_trace_ray(const PtoPrepared *p, const float *od, int32_t *id, float *t)
 {
-    Counters cn = {0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, NULL, 0, 0};
     Ray r = create_ray(pt_make3(od[0], od[1], od[2]), pt_make3(od[3], od[4], od[5]));
     RayHit h = trace(p, &r, &cn);
     *id = h.id; *t = h.distance;
@@ -554,6 +572,15 @@ void pto_sky_sample(const PtoPrepared *p, const float *d, float *rgb)
     Ray r = create_ray(pt_make3(0, 0, 0), pt_make3(d[0], d[1], d[2]));
     f3 c = skybox_sample(p, &r);
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+
+/* Every Trace() of one pixel, in order: 8 floats per call (origin, direction, id, distance). */
+int pto_path_dump(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, int idx, int idy, float *log, int cap)
+{
+    Counters cn = {0, 0, 0, 0, log, cap, 0};
+    float out4[4]; int32_t id;
+    cs_main(p, prm, W, H, idx, idy, out4, &id, &cn);
+    return cn.log_n;
 }
 
 float pto_fmath(int which, float a, float b)

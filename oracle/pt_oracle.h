@@ -65,6 +65,9 @@ void pto_camera_ray(const float *cam_to_world, const float *cam_inv_proj,
                     int id_x, int id_y, int width, int height, float *origin_dir6); /* SH:108-120,842 */
 void pto_trace_ray(const PtoPrepared *p, const float *origin_dir6, int32_t *id_out, float *t_out);
 void pto_sky_sample(const PtoPrepared *p, const float *dir3, float *rgb_out);        /* SH:324-332 */
+/* Every Trace() call of one pixel in order, 8 floats each: origin, direction, hit id, distance. Returns the count. */
+int pto_path_dump(const PtoPrepared *p, const PtFrameParams *params, int width, int height, int id_x, int id_y,
+                  float *log8, int capacity);
 float pto_fmath(int which, float a, float b); /* 0 sin 1 cos 2 pow 3 acos 4 atan2 5 log2 6 exp2 */
 
 #ifdef __cplusplus

@@ -49,6 +49,8 @@ def lib():
         L.pto_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pto_trace_ray.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.pto_sky_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pto_path_dump.restype = C.c_int
+        L.pto_path_dump.argtypes = [C.c_void_p, C.POINTER(PtFrameParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.pto_fmath.restype = C.c_float
         L.pto_fmath.argtypes = [C.c_int, C.c_float, C.c_float]
         _lib = L
@@ -105,6 +107,11 @@ class Oracle:
             lib().pto_trace_ray(self._p, od[k].ctypes.data, C.byref(i), C.byref(t))
             ids[k] = i.value; ts[k] = t.value
         return ids, ts
+
+    def path_dump(self, params, width, height, x, y, cap=4096):
+        log = np.zeros((cap, 8), np.float32)
+        n = lib().pto_path_dump(self._p, C.byref(params), width, height, x, y, log.ctypes.data, cap)
+        return log[:n]
 
     def sky_sample(self, d):
         d = np.ascontiguousarray(d, np.float32); out = np.zeros(3, np.float32)

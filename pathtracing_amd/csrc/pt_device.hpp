@@ -61,7 +61,7 @@ __device__ __forceinline__ f3 xyz(float4 q) { return pt_make3(q.x, q.y, q.z); }
 // ------------------------------------------------------------------ traversal
 
 struct Stack {
-    uint32_t *lds;                 // &stack[0][lane]; entry e at lds[e * 64]... see STRIDE
+    uint32_t *lds;                 // &stack[0][lane]; entry e at lds[e * kStackStride]
     int32_t spill[kStackSpill];
     int sp;
 };
@@ -125,7 +125,13 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
                                          uint32_t &recbest, Stack &st, uint32_t &n_nodes, uint32_t &n_prims)
 {
     if (sc.n_nodes == 0) return;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    // Slab tests use 1/d with |d| clamped away from zero: an infinite reciprocal would turn
+    // lo*inv - o*inv into inf - inf.  Moving an axis-parallel ray by 1e-18 per unit length is
+    // far inside the padding of the boxes.
+    const float kTiny = 1e-18f;
+    const float ix = 1.0f / (pt_abs(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x);
+    const float iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
+    const float iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
     st.sp = 0;
     int32_t node = 0;

@@ -34,6 +34,7 @@ def test_fixture_image_bit_exact(tracer, fixture_scene, spp, maxb):
     W, H = 64, 36
     tracer.resize(W, H)
     p = pa.make_params(s, W, H, seed=0.5, spp=spp, max_bounces=maxb)
+    tracer.stats()   # counters run from the previous pt_get_stats: start a fresh epoch
     tracer.render(p)
     g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
     c, cid, cst = orc.render(p, W, H, threads=4)
@@ -135,6 +136,7 @@ def test_mesh_scene_against_oracle_bvh(tracer, sky_small):
     W, H = 256, 144
     tracer.resize(W, H)
     p = pa.make_params(s, W, H, seed=0.5, spp=2, max_bounces=8)
+    tracer.stats()   # counters run from the previous pt_get_stats: start a fresh epoch
     tracer.render(p)
     g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
     orc = po.Oracle.from_scene(s, sky_small, accel=True)
