@@ -1,0 +1,136 @@
+"""Host side above the C ABI: scene procedure (RayTracingMaster.cs:315-369), mesh flattening
+(:371-413), camera matrices (:489-490) and the master's per-frame parameters (:455-540)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pathtracing_amd as pa
+from pathtracing_amd import _ffi
+
+
+def test_sphere_field_procedure():
+    s = pa.Scene("spheres")
+    sp = s.spheres
+    assert 20 < len(sp) <= 100
+    pos, r = sp[:, :3], sp[:, 3]
+    assert ((r >= 3.0) & (r <= 8.0)).all()
+    assert np.array_equal(pos[:, 1], r)                                  # resting on the plane (M:328)
+    assert (np.hypot(pos[:, 0], pos[:, 2]) <= 100.0 + 1e-3).all()        # insideUnitCircle * placement radius
+    d = np.linalg.norm(pos[:, None] - pos[None], axis=-1) + np.eye(len(sp)) * 1e9
+    assert (d >= (r[:, None] + r[None]) - 1e-4).all()                    # rejection of overlaps (M:331-336)
+    albedo, spec, smooth, emis = sp[:, 4:7], sp[:, 7:10], sp[:, 10], sp[:, 11:14]
+    metal = (albedo == 0).all(1) & (spec > 0).any(1)
+    diel = np.isclose(spec, 0.04).all(1)
+    emit = (emis > 0).any(1)
+    assert (metal | diel | emit).all() and not (emit & (metal | diel)).any()
+    assert (emis[emit].max(1) >= 3.0 - 1e-4).all() and (emis[emit].max(1) <= 8.0 + 1e-4).all()   # ColorHSV(..., 3, 8)
+    assert ((albedo[emit] == 0).all() and (spec[emit] == 0).all())
+    assert ((smooth >= 0) & (smooth <= 1)).all()
+    # deterministic for a given seed, different for another
+    a = np.zeros((200, 14), np.float32); b = np.zeros((200, 14), np.float32); c = np.zeros((200, 14), np.float32)
+    lib = _ffi.ptmaster()
+    na = lib.ptm_sphere_field(207407, 100, 3.0, 8.0, 100.0, a.ctypes.data, 200)
+    nb = lib.ptm_sphere_field(207407, 100, 3.0, 8.0, 100.0, b.ctypes.data, 200)
+    nc = lib.ptm_sphere_field(1, 100, 3.0, 8.0, 100.0, c.ctypes.data, 200)
+    assert na == nb == len(sp) and (a == b).all() and (a[:na] == sp).all() and not (a[:min(na, nc)] == c[:min(na, nc)]).all()
+
+
+def test_scene_sizes():
+    assert pa.Scene("blob70k").n_triangles == 69936
+    h = pa.Scene("hall260k")
+    assert h.n_triangles == 262480
+    x = pa.Scene("xr")
+    assert x.n_triangles == 12 and len(x.objects) == 1 and len(x.spheres) > 30
+    with pytest.raises(ValueError):
+        pa.Scene("nope")
+
+
+def test_mesh_flattening_offsets_indices_like_the_reference():
+    """indices are stored already offset by the mesh's first vertex (RayTracingMaster.cs:392-399)."""
+    s = pa.Scene("fixture")
+    n0 = len(s.vertices)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "quad.obj")
+        open(path, "w").write("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+        s.add_obj(path)
+    assert len(s.objects) == 2 and len(s.vertices) == n0 + 4
+    o = s.objects[1]
+    assert o["offset"] == s.objects[0]["count"] and o["count"] == 6      # quad fan-triangulated
+    assert s.indices[o["offset"]:].min() == n0 and s.indices[o["offset"]:].max() == n0 + 3
+
+
+def test_blob_is_wound_outward():
+    s = pa.Scene("fixture")
+    v = s.vertices[s.indices.reshape(-1, 3)]
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    assert (np.einsum("ij,ij->i", n, v.mean(1)) > 0).all()               # blob is centred on the object origin
+
+
+def test_city_scene_instances_share_geometry():
+    s = pa.Scene("city10m")
+    assert len(s.objects) == 38 and s.n_triangles == 38 * 262480
+    assert len(s.indices) == 262480 * 3                                  # one copy of the geometry
+    assert (s.objects["offset"] == 0).all()
+
+
+def test_camera_matrices():
+    eye = np.array([3, 8, -19], np.float32); tgt = np.array([0, 3.8, 0], np.float32)
+    c2w, ip = pa.camera_matrices(eye, tgt, 60.0, 16 / 9)
+    M = c2w.reshape(4, 4).T
+    R = M[:3, :3]
+    assert np.allclose(R.T @ R, np.eye(3), atol=1e-6) and np.isclose(np.linalg.det(R), 1.0, atol=1e-6)
+    assert np.allclose(M[:3, 3], eye)
+    fwd = (tgt - eye) / np.linalg.norm(tgt - eye)
+    assert np.allclose(-R[:, 2], fwd, atol=1e-6)                         # camera looks down -Z (OpenGL convention)
+    # inverse projection: P^-1 * (u, v, 0, 1) = (u*aspect*tan, v*tan, -1, .)
+    P = ip.reshape(4, 4).T
+    t = np.tan(np.radians(30.0))
+    assert np.allclose(P @ np.array([0.5, -0.25, 0, 1]), [0.5 * 16 / 9 * t, -0.25 * t, -1, (100 + 0.1) / (2 * 100 * 0.1)], rtol=1e-5)
+    # and it really is the inverse of the OpenGL perspective matrix
+    n, f, a = 0.1, 100.0, 16 / 9
+    proj = np.array([[1 / (a * t), 0, 0, 0], [0, 1 / t, 0, 0], [0, 0, (f + n) / (n - f), 2 * f * n / (n - f)], [0, 0, -1, 0]])
+    assert np.allclose(proj @ P, np.eye(4), atol=1e-4)
+
+
+def test_frame_seed():
+    assert pa.frame_seed(0) == 0.5
+    for k in (1, 2, 17, 1000):
+        want = (0.5 + k * 0.6180339) % 1.0
+        assert abs(pa.frame_seed(k) - want) < 1e-6
+        assert 0.0 <= pa.frame_seed(k) < 1.0
+
+
+def test_procedural_sky_is_deterministic_and_bright_at_the_sun():
+    a = pa.procedural_sky(64, 32); b = pa.procedural_sky(64, 32)
+    assert (a == b).all() and np.isfinite(a).all() and (a[..., :3] >= 0).all()
+    assert a[..., 0].max() > 2.0 and a[..., :3].min() < 0.5
+
+
+def test_master_parameters_without_a_gpu():
+    """SetShaderParameters of the C++ mirror: per-frame seed, spp rule, depth flag, sample counter."""
+    lib = _ffi.ptmaster()
+    h = C.c_void_p()
+    rc = lib.ptm_master_create(0, C.byref(h))
+    try:
+        lib.ptm_master_configure(h, 1920, 1080, 4, 8, 0, pa.PT_ACCUM_ADDMAT, 10)
+        eye = (C.c_float * 3)(0, 4.6, 0); tgt = (C.c_float * 3)(0, 4.6, 1)
+        lib.ptm_master_set_camera(h, eye, tgt, 90.0, -0.011)
+        p = pa.PtFrameParams()
+        lib.ptm_master_peek_params(h, C.byref(p))
+        assert p.samples_per_pixel == 4 and p.max_bounces == 8 and p.depth == 0 and p.render_mode == 1
+        assert p.seed == 0.5 and p.sample_index == 0 and p.accumulate == pa.PT_ACCUM_ADDMAT
+        c2w = np.array(p.camera_to_world[:]).reshape(4, 4).T
+        # left eye: shifted by -0.011 along camera right; looking down +z with up +y, camera right is world -x
+        assert np.isclose(abs(c2w[0, 3]), 0.011, atol=1e-6) and np.isclose(c2w[1, 3], 4.6)
+        want_c2w, want_ip = pa.camera_matrices((c2w[0, 3], 4.6, 0), (c2w[0, 3], 4.6, 1), 90.0, 1920 / 1080)
+        assert np.allclose(p.camera_to_world[:], want_c2w) and np.allclose(p.camera_inverse_projection[:], want_ip)
+        lib.ptm_master_configure(h, 1920, 1080, 4, 8, 1, pa.PT_ACCUM_ADDMAT, 10)     # depth on
+        lib.ptm_master_peek_params(h, C.byref(p))
+        assert p.depth == 1 and p.accumulate == pa.PT_ACCUM_NONE and p.sample_index == 0   # M:805: depth ? 0 : _currentSample
+        if rc != 0:
+            assert b"pt_create" in lib.ptm_master_error(h)     # no GPU here: the error is reported, nothing rendered
+            assert lib.ptm_master_render(h) != 0
+    finally:
+        lib.ptm_master_destroy(h)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the CPU oracle (run here, committed).
+
+The reference ships no golden data (it has no tests at all), so these vectors pin
+the oracle against regressions and give the GPU tests a fixed target; they are
+NOT outputs of the reference itself.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pathtracing_amd as pa  # noqa: E402
+from oracle import pt_oracle as po  # noqa: E402
+
+out = os.path.join(ROOT, "tests", "golden")
+os.makedirs(out, exist_ok=True)
+
+# (i) rand(): first 16 draws at seed 0.5 for four pixels of a 1080p frame
+pix = [(0, 0), (1, 0), (959, 539), (1919, 1079)]
+rand = np.stack([po.rand_sequence(0.5, x, y, 16) for x, y in pix])
+
+# (ii) camera rays at the corners and centre, fov 90, near .1, far 100 (TestScene.unity:851-853)
+c2w, ip = pa.camera_matrices((0, 4.6, 0), (0, 4.6, 1), 90.0, 1920 / 1080, z_near=0.1, z_far=100.0)
+cam_px = [(0, 0), (1919, 0), (0, 1079), (1919, 1079), (960, 540)]
+cam = np.stack([po.camera_ray(c2w, ip, x, y, 1920, 1080) for x, y in cam_px])
+
+# (v) fixture scene, 64x36: hit ids, depth, 1-spp (4 and 8 bounces) and 16-spp images
+s = pa.Scene("fixture")
+sky = pa.procedural_sky(128, 64)
+o = po.Oracle.from_scene(s, sky)
+W, H = 64, 36
+res = {}
+for name, kw in {"spp1_b4": dict(spp=1, max_bounces=4), "spp1_b8": dict(spp=1, max_bounces=8),
+                 "spp16_b8": dict(spp=16, max_bounces=8), "depth": dict(depth=1)}.items():
+    img, ids, st = o.render(pa.make_params(s, W, H, seed=0.5, **kw), W, H, threads=4)
+    res[name] = img
+    res[name + "_rays"] = np.array([st["rays"], st["trace_calls"], st["paths"]], np.int64)
+    res["ids"] = ids
+np.savez_compressed(os.path.join(out, "fixture_64x36.npz"), rand_pixels=np.array(pix), rand=rand, cam_c2w=c2w, cam_ip=ip,
+                    cam_pixels=np.array(cam_px), cam_rays=cam, **res)
+print("wrote", os.path.join(out, "fixture_64x36.npz"), {k: v.shape for k, v in res.items()})
