@@ -47,12 +47,13 @@ struct RenderArgs {
     int32_t accumulate;
     uint32_t sample_index;
     uint32_t *work_counter;
+    uint32_t *stack_overflow;     // kStackOverflow * (threads in the grid) entries
     unsigned long long *stats;    // [0] rays [1] nodes [2] prims [3] paths
 };
 
 constexpr int kBlock = 256;            // 4 waves
-constexpr int kStackLds = 24;          // traversal stack entries kept in LDS per lane
-constexpr int kStackSpill = 40;        // further entries in private memory (depth bound: bvh.hpp kMaxDepth)
+constexpr int kStackLds = 16;          // traversal stack entries kept in LDS per lane
+constexpr int kStackOverflow = 48;     // further entries in a global buffer (depth bound: bvh.hpp kMaxDepth)
 
 __device__ __forceinline__ float as_f(int32_t i) { return __int_as_float(i); }
 __device__ __forceinline__ int32_t as_i(float f) { return __float_as_int(f); }
@@ -60,24 +61,27 @@ __device__ __forceinline__ f3 xyz(float4 q) { return pt_make3(q.x, q.y, q.z); }
 
 // ------------------------------------------------------------------ traversal
 
+// Traversal stack of one lane: the first kStackLds entries live in LDS (entry e of
+// thread t at lds[e * kBlock + t]: consecutive lanes hit consecutive banks), deeper
+// entries in a global overflow buffer laid out [entry][global thread] so that a
+// wave's accesses coalesce.  bvh.hpp's kMaxDepth bounds the total.
 struct Stack {
-    uint32_t *lds;                 // &stack[0][lane]; entry e at lds[e * kStackStride]
-    int32_t spill[kStackSpill];
-    int sp;
+    uint32_t *lds;        // &lds_stack[threadIdx.x]
+    uint32_t *overflow;   // &overflow[global thread id]
+    uint32_t stride;      // threads in the grid
 };
-constexpr int kStackStride = kBlock;  // entries of one lane are kBlock dwords apart (bank = lane % 32)
 
-__device__ __forceinline__ void stack_push(Stack &s, int32_t v)
+__device__ __forceinline__ void stack_push(const Stack &s, int &sp, int32_t v)
 {
-    if (s.sp < kStackLds) s.lds[s.sp * kStackStride] = (uint32_t)v;
-    else if (s.sp < kStackLds + kStackSpill) s.spill[s.sp - kStackLds] = v;
-    s.sp++;  // beyond capacity the entry is dropped; the builder's depth bound makes that unreachable
+    if (sp < kStackLds) s.lds[sp * kBlock] = (uint32_t)v;
+    else if (sp < kStackLds + kStackOverflow) s.overflow[(size_t)(sp - kStackLds) * s.stride] = (uint32_t)v;
+    sp++;  // beyond capacity the entry is dropped; the builder's depth bound makes that unreachable
 }
-__device__ __forceinline__ int32_t stack_pop(Stack &s)
+__device__ __forceinline__ int32_t stack_pop(const Stack &s, int &sp)
 {
-    s.sp--;
-    if (s.sp < kStackLds) return (int32_t)s.lds[s.sp * kStackStride];
-    if (s.sp < kStackLds + kStackSpill) return s.spill[s.sp - kStackLds];
+    sp--;
+    if (sp < kStackLds) return (int32_t)s.lds[sp * kBlock];
+    if (sp < kStackLds + kStackOverflow) return (int32_t)s.overflow[(size_t)(sp - kStackLds) * s.stride];
     return 0;
 }
 
@@ -122,7 +126,7 @@ __device__ __forceinline__ void intersect_prim(const float4 *prims, uint32_t rec
 // Closest hit over spheres and triangles through the BVH.  tbest/idbest come in
 // holding the ground-plane result (or +inf / -1).
 __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &tbest, int32_t &idbest,
-                                         uint32_t &recbest, Stack &st, uint32_t &n_nodes, uint32_t &n_prims)
+                                         uint32_t &recbest, const Stack &st, uint32_t &n_nodes, uint32_t &n_prims)
 {
     if (sc.n_nodes == 0) return;
     // Slab tests use 1/d with |d| clamped away from zero: an infinite reciprocal would turn
@@ -133,7 +137,7 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
     const float iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
     const float iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
-    st.sp = 0;
+    int sp = 0;
     int32_t node = 0;
     for (;;) {
         while (node >= 0) {
@@ -156,15 +160,15 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
             int32_t cl = as_i(q0.w), cr = as_i(q1.w);
             if (hl && hr) {
                 bool left_first = ln <= rn;
-                stack_push(st, left_first ? cr : cl);
+                stack_push(st, sp, left_first ? cr : cl);
                 node = left_first ? cl : cr;
             } else if (hl) {
                 node = cl;
             } else if (hr) {
                 node = cr;
             } else {
-                if (st.sp == 0) return;
-                node = stack_pop(st);
+                if (sp == 0) return;
+                node = stack_pop(st, sp);
             }
         }
         uint32_t enc = (uint32_t)~node;
@@ -173,8 +177,8 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
             intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
         }
         n_prims += count;
-        if (st.sp == 0) return;
-        node = stack_pop(st);
+        if (sp == 0) return;
+        node = stack_pop(st, sp);
     }
 }
 
@@ -358,10 +362,8 @@ __device__ __forceinline__ void accumulate_pixel(const RenderArgs &a, size_t p, 
 // pixel i%64 inside it, so the 64 items a fresh wave draws are one block.
 __global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
 {
-    __shared__ uint32_t lds_stack[kStackLds * kStackStride];
-    Stack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.sp = 0;
+    __shared__ uint32_t lds_stack[kStackLds * kBlock];
+    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + (blockIdx.x * kBlock + threadIdx.x), gridDim.x * kBlock};
     const int lane = threadIdx.x & 63;
 
     int32_t pix_x = -1, pix_y = 0;   // pix_x < 0: lane has no pixel
@@ -481,11 +483,12 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
 // ------------------------------------------------------- ray-query kernels
 
 // One thread per caller-supplied ray; BVH traversal.
-__global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, const float *od, int n, int32_t *ids, float *ts)
+__global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uint32_t *stack_overflow, const float *od, int n,
+                                                                 int32_t *ids, float *ts)
 {
-    __shared__ uint32_t lds_stack[kStackLds * kStackStride];
-    Stack st; st.lds = lds_stack + threadIdx.x; st.sp = 0;
+    __shared__ uint32_t lds_stack[kStackLds * kBlock];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const Stack st = {lds_stack + threadIdx.x, stack_overflow + i, gridDim.x * kBlock};
     if (i >= n) return;
     f3 o = pt_make3(od[i * 6 + 0], od[i * 6 + 1], od[i * 6 + 2]);
     f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);

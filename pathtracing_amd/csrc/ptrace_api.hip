@@ -43,6 +43,8 @@ struct pt_context {
     int32_t *ids = nullptr;
 
     uint32_t *d_work = nullptr;
+    uint32_t *d_stack_ovf = nullptr;   // traversal stack overflow, kStackOverflow entries per thread
+    size_t stack_ovf_threads = 0;
     unsigned long long *d_stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool epoch_open = false;  // renders issued since the last pt_get_stats
@@ -227,6 +229,18 @@ int validate_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects,
     return PT_OK;
 }
 
+// The traversal stack's overflow area for a launch of `threads` threads.
+int ensure_stack_overflow(pt_context *ctx, size_t threads)
+{
+    if (threads <= ctx->stack_ovf_threads) return PT_OK;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_dev(ctx->d_stack_ovf);
+    ctx->stack_ovf_threads = 0;
+    PT_HIP(ctx, hipMalloc((void **)&ctx->d_stack_ovf, threads * kStackOverflow * sizeof(uint32_t)));
+    ctx->stack_ovf_threads = threads;
+    return PT_OK;
+}
+
 // Close the statistics epoch: wait for the last render, read its counters.
 int finish_epoch(pt_context *ctx)
 {
@@ -293,7 +307,7 @@ void pt_destroy(pt_context *ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_dev(ctx->d_nodes); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
-    free_dev(ctx->d_work); free_dev(ctx->d_stats);
+    free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -444,6 +458,8 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->blocks_per_cu);
+    if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
+    a.stack_overflow = ctx->d_stack_ovf;
     hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -523,11 +539,12 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
         return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
     }
     int grid = (n_rays + kBlock - 1) / kBlock;
+    if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) { cleanup(); return rc; }
     SceneDev sc = scene_dev(ctx);
     if (brute_force)
         hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
     else
-        hipLaunchKernelGGL(trace_rays_bvh_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_od, n_rays, d_id, d_t);
+        hipLaunchKernelGGL(trace_rays_bvh_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(ctx->stream)) != hipSuccess ||
         (e = hipMemcpy(ids_out, d_id, (size_t)n_rays * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
         (e = hipMemcpy(t_out, d_t, (size_t)n_rays * 4, hipMemcpyDeviceToHost)) != hipSuccess) {
