@@ -122,6 +122,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
+    accum.zero_()
     tr.stats()                      # close the statistics epoch of the warm-up
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -118,6 +118,13 @@ const char *pt_last_error(const pt_context *ctx);
  * the context's own; NULL restores the context's stream. */
 int pt_set_stream(pt_context *ctx, void *hip_stream);
 
+/* Implementation switches; no counterpart in the reference.
+ *   "backend"  1 (default): wavefront stages - generate / persistent trace / shade+compact+regenerate;
+ *              0: one persistent kernel that does everything per lane.
+ * Both produce the same image bit for bit.  The environment variable PTRACE_BACKEND=mega selects 0
+ * at pt_create. */
+int pt_set_option(pt_context *ctx, const char *name, int value);
+
 /* _Spheres: new ComputeBuffer(count,56).SetData + SetBuffer (RayTracingMaster.cs:366-367,536).
  * count == 0 is valid (buffer not bound, RayTracingMaster.cs:445). */
 int pt_set_spheres(pt_context *ctx, const PtSphere *spheres, int count);

@@ -49,6 +49,7 @@ PTRACE_SYMBOLS = {
     "pt_destroy": (None, [_ctx]),
     "pt_last_error": (C.c_char_p, [_ctx]),
     "pt_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "pt_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
     "pt_set_spheres": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pt_set_meshes": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "pt_update_transforms": (C.c_int, [_ctx, C.c_void_p, C.c_int]),

@@ -49,6 +49,20 @@ struct RenderArgs {
     uint32_t *work_counter;
     uint32_t *stack_overflow;     // kStackOverflow * (threads in the grid) entries
     unsigned long long *stats;    // [0] rays [1] nodes [2] prims [3] paths
+    // wavefront pipeline state, one slot per work item (pt_wavefront.hpp)
+    float4 *ray_o;                // (origin.xyz, _Seed)
+    float4 *ray_d;                // (direction.xyz, bits(sample | bounce << 24))
+    float4 *hit;                  // (t, bits(id), bits(record), 0)
+    float4 *path_e;               // (energy.xyz, primary-hit distance)
+    float4 *path_r;               // (result.xyz, bits(primary id))
+    const uint32_t *q_in;         // slots with a ray to trace this iteration
+    uint32_t *q_out;              // slots with a ray for the next iteration
+    uint32_t *counts;             // counts[i] = entries of the queue of iteration i
+    uint32_t *cursors;            // cursors[i] = next unclaimed queue index of iteration i
+    int32_t iter;
+    int32_t refill_threshold;     // wf_trace refills a wave once this many lanes are idle
+    int32_t node_vote;            // wf_trace leaves the inner-node loop when fewer lanes than this hold an inner node
+    int32_t vote_shade, vote_node; // path_sched_kernel phase thresholds
 };
 
 constexpr int kBlock = 256;            // 4 waves
@@ -281,23 +295,32 @@ __device__ __forceinline__ f3 shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f
     float specChance = pt_dot3(specular, pt_make3(third, third, third));
     float diffChance = pt_dot3(albedo, pt_make3(third, third, third));
     float roulette = rng_next(rs);
-    if (roulette < specChance) {
+    // SH:345-365.  The specular and the diffuse branch both end in SampleHemisphere(); they are
+    // merged here so that a wave runs that code once, each lane with its own axis and alpha.
+    const bool spec = roulette < specChance;
+    const bool diff = !spec && diffChance > 0 && roulette < specChance + diffChance;
+    if (spec || diff) {
         o = pt_along3(position, 0.001f, normal);
-        float alpha = pt_pow(1000.0f, smoothness * smoothness);
-        d = sample_hemisphere(rs, pt_reflect3(d, normal), alpha);
-        float f = (alpha + 2) / (alpha + 1);
-        float k = 1.0f / specChance;
-        float sd = pt_saturate(pt_dot3(normal, d) * f);
-        energy.x *= (k * specular.x) * sd;
-        energy.y *= (k * specular.y) * sd;
-        energy.z *= (k * specular.z) * sd;
-    } else if (diffChance > 0 && roulette < specChance + diffChance) {
-        o = pt_along3(position, 0.001f, normal);
-        d = sample_hemisphere(rs, normal, 1.0f);
-        float k = 1.0f / diffChance;
-        energy.x *= k * albedo.x;
-        energy.y *= k * albedo.y;
-        energy.z *= k * albedo.z;
+        float alpha = 1.0f;
+        f3 axis = normal;
+        if (spec) {
+            alpha = pt_pow(1000.0f, smoothness * smoothness);
+            axis = pt_reflect3(d, normal);
+        }
+        d = sample_hemisphere(rs, axis, alpha);
+        if (spec) {
+            float f = (alpha + 2) / (alpha + 1);
+            float k = 1.0f / specChance;
+            float sd = pt_saturate(pt_dot3(normal, d) * f);
+            energy.x *= (k * specular.x) * sd;
+            energy.y *= (k * specular.y) * sd;
+            energy.z *= (k * specular.z) * sd;
+        } else {
+            float k = 1.0f / diffChance;
+            energy.x *= k * albedo.x;
+            energy.y *= k * albedo.y;
+            energy.z *= k * albedo.z;
+        }
     } else {
         energy = pt_make3(0, 0, 0);
     }
@@ -316,6 +339,23 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, int px, int py, 
     dir.z = pt_fma(a.ip[6], v, a.ip[2] * u) + a.ip[14];
     dir = pt_mul_dir(a.c2w, dir);
     d = pt_normalize3(dir);
+}
+
+// Work item i -> 8x8 pixel block i/64 of the tile rectangle (row-major blocks), pixel i%64 inside
+// it, so 64 consecutive items are one block.  Returns false for items outside the rectangle.
+__device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, int &x, int &y)
+{
+    uint32_t blk = item >> 6, in = item & 63u;
+    int bx = (int)(blk % (uint32_t)a.tiles_x), by = (int)(blk / (uint32_t)a.tiles_x);
+    x = a.tx0 + bx * 8 + (int)(in & 7u);
+    y = a.ty0 + by * 8 + (int)(in >> 3);
+    return x < a.tx0 + a.tw && y < a.ty0 + a.th;
+}
+
+// dot(_Pixel, float2(12.9898, 78.233)) with _Pixel = id.xy * 2 (SH:831, SH:52)
+__device__ __forceinline__ float pixel_dot(int x, int y)
+{
+    return pt_fma((float)y * 2.0f, 78.233f, ((float)x * 2.0f) * 12.9898f);
 }
 
 // Converged-image update fused into the final write: AddMat.shader:44-63 with
@@ -349,6 +389,16 @@ __device__ __forceinline__ void accumulate_pixel(const RenderArgs &a, size_t p, 
     a.converged[p] = out;
 }
 
+// Counter totals go to one of kStatsShards copies (picked by block id) so that thousands of waves
+// finishing together do not queue on one address; the host adds the copies up.
+constexpr int kStatsShards = 64;
+constexpr int kStatsStride = 8;   // u64 words per shard: rays, nodes, prims, paths, (unused)
+__device__ __forceinline__ void stats_add(unsigned long long *stats, int which, uint32_t v, int lane)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0 && v && stats) atomicAdd(&stats[(blockIdx.x % kStatsShards) * kStatsStride + which], (unsigned long long)v);
+}
+
 // --------------------------------------------------------------- path kernel
 //
 // Persistent kernel: the grid is sized to fill the chip once; every lane owns
@@ -379,7 +429,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
     uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_paths = 0;
 
     for (;;) {
-        // ---- refill idle lanes with new pixels (wave-aggregated counter bump)
+        // ---- refill idle lanes with new pixels: one wave-aggregated bump of the global counter for
+        //      exactly the lanes that need one (finest-grained balancing; coarser per-wave chunks
+        //      measured 2x slower because the last chunks serialise)
         bool need = pix_x < 0 && !dead;
         unsigned long long m = __ballot(need);
         if (m) {
@@ -392,14 +444,12 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
                 if (item >= a.total_items) {
                     dead = true;
                 } else {
-                    uint32_t blk = item >> 6, in = item & 63u;
-                    int bx = (int)(blk % (uint32_t)a.tiles_x), by = (int)(blk / (uint32_t)a.tiles_x);
-                    int x = a.tx0 + bx * 8 + (int)(in & 7u), y = a.ty0 + by * 8 + (int)(in >> 3);
-                    if (x < a.tx0 + a.tw && y < a.ty0 + a.th) {
+                    int x, y;
+                    if (item_pixel(a, item, x, y)) {
                         pix_x = x; pix_y = y;
                         sample = 0; bounce = 0;
                         rs.seed = a.seed;
-                        rs.dotp = pt_fma((float)y * 2.0f, 78.233f, ((float)x * 2.0f) * 12.9898f);  // SH:831, SH:52
+                        rs.dotp = pixel_dot(x, y);
                         result = pt_make3(0, 0, 0);
                         energy = pt_make3(1, 1, 1);
                         camera_ray(a, x, y, o, d);
@@ -465,19 +515,196 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
         }
     }
 
-    // ---- counters: one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) {
-        c_rays += __shfl_down(c_rays, off);
-        c_nodes += __shfl_down(c_nodes, off);
-        c_prims += __shfl_down(c_prims, off);
-        c_paths += __shfl_down(c_paths, off);
+    stats_add(a.stats, 0, c_rays, lane);
+    stats_add(a.stats, 1, c_nodes, lane);
+    stats_add(a.stats, 2, c_prims, lane);
+    stats_add(a.stats, 3, c_paths, lane);
+}
+
+// ------------------------------------------------- scheduled path kernel
+//
+// The same persistent one-pixel-per-lane path tracer as path_kernel, but the wave no longer
+// walks "trace everyone, then shade everyone".  Every lane is in one of four states -
+// holding an inner BVH node, holding a leaf, holding a finished ray that waits for Shade(),
+// or idle - and each round the wave runs the ONE phase that most lanes can take part in:
+//
+//   shade phase   when at least `vote_shade` lanes wait (or nothing else is runnable):
+//                 Shade() for finished rays, new pixels for idle lanes, ray set-up
+//   node phase    when at least `vote_node` lanes hold an inner node (or no lane holds a leaf)
+//   leaf phase    otherwise
+//
+// A lane whose ray ends early therefore waits only until enough other lanes have ended too,
+// not until the longest ray of the wave is done, and the expensive shading code runs with
+// many lanes active.  Per-pixel arithmetic and its order are unchanged.
+constexpr int kDoneNodeSm = (int)0x80000000;
+
+__global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
+{
+    __shared__ uint32_t lds_stack[kStackLds * kBlock];
+    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + (blockIdx.x * kBlock + threadIdx.x), gridDim.x * kBlock};
+    const int lane = threadIdx.x & 63;
+    const SceneDev &sc = a.sc;
+
+    int32_t pix_x = -1, pix_y = 0;       // pix_x < 0: no pixel
+    bool dead = false;                    // no pixel and none left to fetch
+    int32_t sample = 0, bounce = 0;
+    float seed = 0.0f;
+    f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1), energy = pt_make3(0, 0, 0), result = pt_make3(0, 0, 0);
+    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+    const f3 cam_o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
+    float alpha_dist = 0.0f;
+    int32_t primary_id = -1;
+    float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
+    int32_t node = kDoneNodeSm; int sp = 0;   // node == kDoneNodeSm with a pixel: ray finished, waits for Shade()
+    const float fspp = (float)a.spp;
+    uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_paths = 0;
+
+    for (;;) {
+        const bool has_pixel = pix_x >= 0;
+        const bool inner = has_pixel && node >= 0;
+        const bool leaf = has_pixel && node < 0 && node != kDoneNodeSm;
+        const bool waiting = (has_pixel && node == kDoneNodeSm) || (!has_pixel && !dead);
+        const int n_inner = __popcll(__ballot(inner)), n_leaf = __popcll(__ballot(leaf)), n_wait = __popcll(__ballot(waiting));
+        if (n_inner + n_leaf + n_wait == 0) break;
+
+        if (n_wait >= a.vote_shade || n_inner + n_leaf == 0) {
+            // ================= shade phase =================
+            bool new_ray = false;
+            if (has_pixel && node == kDoneNodeSm) {
+                if (a.depth == 1) {                                   // SH:799-809
+                    size_t p = (size_t)pix_y * a.W + pix_x;
+                    float dis = tbest / 16.0f;
+                    a.result[p] = make_float4(dis, dis, dis, dis);
+                    if (a.hit_ids) a.hit_ids[p] = idbest;
+                    pix_x = -1;
+                } else {
+                    Rng rs = {seed, pixel_dot(pix_x, pix_y)};
+                    f3 e = energy, hit_pos;                           // SH:866: energy read before Shade()
+                    f3 s = shade(sc, rs, o, d, energy, tbest, idbest, recbest, hit_pos);
+                    seed = rs.seed;
+                    result.x += e.x * s.x / fspp;
+                    result.y += e.y * s.y / fspp;
+                    result.z += e.z * s.z / fspp;
+                    bool path_done;
+                    if (bounce == 0) {
+                        primary_id = idbest;
+                        alpha_dist = pt_length3(pt_sub3(hit_pos, cam_o));
+                        path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see path_kernel
+                    } else {
+                        path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
+                    }
+                    bounce++;
+                    new_ray = true;
+                    if (path_done) {
+                        sample++;
+                        if (sample < a.spp) {                          // next sample of the same pixel, SH:839
+                            bounce = 0;
+                            energy = pt_make3(1, 1, 1);
+                            camera_ray(a, pix_x, pix_y, o, d);
+                            c_paths++;
+                        } else {                                       // SH:933-936
+                            size_t p = (size_t)pix_y * a.W + pix_x;
+                            float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
+                            a.result[p] = fresh;
+                            if (a.hit_ids) a.hit_ids[p] = primary_id;
+                            accumulate_pixel(a, p, fresh);
+                            pix_x = -1;
+                            new_ray = false;
+                        }
+                    }
+                }
+            }
+            // ---- new pixels for lanes without one
+            bool need = pix_x < 0 && !dead;
+            unsigned long long m = __ballot(need);
+            if (m) {
+                int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(a.work_counter, (uint32_t)__popcll(m));
+                base = __shfl(base, leader);
+                if (need) {
+                    uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (item >= a.total_items) {
+                        dead = true;
+                    } else {
+                        int x, y;
+                        if (item_pixel(a, item, x, y)) {
+                            pix_x = x; pix_y = y;
+                            sample = 0; bounce = 0;
+                            seed = a.seed;
+                            result = pt_make3(0, 0, 0);
+                            energy = pt_make3(1, 1, 1);
+                            camera_ray(a, x, y, o, d);
+                            c_paths++;
+                            new_ray = true;
+                        }
+                    }
+                }
+            }
+            // ---- set up traversal of the new rays (SH:262-269: plane first)
+            if (new_ray) {
+                tbest = PT_INF; idbest = -1; recbest = 0;
+                intersect_ground_plane(o, d, tbest, idbest);
+                const float kTiny = 1e-18f;   // see traverse()
+                ix = 1.0f / (pt_abs(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x);
+                iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
+                iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
+                ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
+                sp = 0;
+                node = sc.n_nodes ? 0 : kDoneNodeSm;
+                c_rays++;
+            }
+            continue;
+        }
+
+        if (n_inner >= a.vote_node || n_leaf == 0) {
+            // ================= node phase =================
+            if (inner) {
+                const float4 *q = sc.nodes + (size_t)node * 4;
+                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                c_nodes++;
+                float l0x = __builtin_fmaf(q0.x, ix, ox), l1x = __builtin_fmaf(q1.x, ix, ox);
+                float l0y = __builtin_fmaf(q0.y, iy, oy), l1y = __builtin_fmaf(q1.y, iy, oy);
+                float l0z = __builtin_fmaf(q0.z, iz, oz), l1z = __builtin_fmaf(q1.z, iz, oz);
+                float r0x = __builtin_fmaf(q2.x, ix, ox), r1x = __builtin_fmaf(q3.x, ix, ox);
+                float r0y = __builtin_fmaf(q2.y, iy, oy), r1y = __builtin_fmaf(q3.y, iy, oy);
+                float r0z = __builtin_fmaf(q2.z, iz, oz), r1z = __builtin_fmaf(q3.z, iz, oz);
+                float ln = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), 0.0f));
+                float lf = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fmaxf(l0z, l1z));
+                float rn = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), 0.0f));
+                float rf = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fmaxf(r0z, r1z));
+                bool hl = ln <= lf * 1.000002f && ln <= tbest;
+                bool hr = rn <= rf * 1.000002f && rn <= tbest;
+                int32_t cl = as_i(q0.w), cr = as_i(q1.w);
+                if (hl && hr) {
+                    bool left_first = ln <= rn;
+                    stack_push(st, sp, left_first ? cr : cl);
+                    node = left_first ? cl : cr;
+                } else if (hl) {
+                    node = cl;
+                } else if (hr) {
+                    node = cr;
+                } else {
+                    node = sp ? stack_pop(st, sp) : kDoneNodeSm;
+                }
+            }
+            continue;
+        }
+
+        // ================= leaf phase =================
+        if (leaf) {
+            uint32_t enc = (uint32_t)~node;
+            uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
+            c_prims += count;
+            node = sp ? stack_pop(st, sp) : kDoneNodeSm;
+        }
     }
-    if (lane == 0 && a.stats) {
-        atomicAdd(&a.stats[0], (unsigned long long)c_rays);
-        atomicAdd(&a.stats[1], (unsigned long long)c_nodes);
-        atomicAdd(&a.stats[2], (unsigned long long)c_prims);
-        atomicAdd(&a.stats[3], (unsigned long long)c_paths);
-    }
+
+    stats_add(a.stats, 0, c_rays, lane);
+    stats_add(a.stats, 1, c_nodes, lane);
+    stats_add(a.stats, 2, c_prims, lane);
+    stats_add(a.stats, 3, c_paths, lane);
 }
 
 // ------------------------------------------------------- ray-query kernels

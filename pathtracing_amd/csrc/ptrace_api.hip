@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -14,6 +15,7 @@
 #include "../../include/ptrace.h"
 #include "bvh.hpp"
 #include "pt_device.hpp"
+#include "pt_wavefront.hpp"
 
 using namespace ptrace;
 
@@ -50,6 +52,19 @@ struct pt_context {
     bool epoch_open = false;  // renders issued since the last pt_get_stats
     PtStats stats{};
     int num_cus = 0, blocks_per_cu = 0;
+
+    // wavefront pipeline
+    int refill_threshold = 32;
+    int node_vote = 8;
+    int vote_shade = 16, vote_node = 8;
+    int sched_blocks_per_cu = 0;
+    int backend = 1;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
+    int trace_blocks_per_cu = 0, shade_blocks_per_cu = 0;
+    float4 *wf_state = nullptr;            // 5 float4 arrays of wf_slots entries
+    uint32_t *wf_queues = nullptr;         // 2 queues of wf_slots entries
+    size_t wf_slots = 0;
+    uint32_t *wf_counters = nullptr;       // counts[wf_iters + 2] then cursors[wf_iters + 2]
+    size_t wf_iters = 0;
 };
 
 namespace {
@@ -241,6 +256,60 @@ int ensure_stack_overflow(pt_context *ctx, size_t threads)
     return PT_OK;
 }
 
+int ensure_wavefront_state(pt_context *ctx, size_t slots, size_t iters)
+{
+    if (slots > ctx->wf_slots) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_dev(ctx->wf_state); free_dev(ctx->wf_queues);
+        ctx->wf_slots = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->wf_state, slots * 5 * sizeof(float4)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->wf_queues, slots * 2 * sizeof(uint32_t)));
+        ctx->wf_slots = slots;
+    }
+    if (iters > ctx->wf_iters) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_dev(ctx->wf_counters);
+        ctx->wf_iters = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->wf_counters, (iters + 2) * 2 * sizeof(uint32_t)));
+        ctx->wf_iters = iters;
+    }
+    return PT_OK;
+}
+
+// Wavefront backend: generate, then (trace, shade) per iteration.  A pixel traces at most
+// spp * max_bounces rays, one per iteration, which bounds the iteration count; iterations whose
+// queue is empty return at once.
+int render_wavefront(pt_context *ctx, RenderArgs &a)
+{
+    const size_t iters = (size_t)a.spp * (size_t)a.maxb;
+    int rc;
+    if ((rc = ensure_wavefront_state(ctx, a.total_items, iters))) return rc;
+    const int trace_grid = ctx->num_cus * ctx->trace_blocks_per_cu;
+    const int64_t item_blocks = ((int64_t)a.total_items + kBlock - 1) / kBlock;
+    const int shade_grid = (int)std::min<int64_t>(item_blocks, (int64_t)ctx->num_cus * ctx->shade_blocks_per_cu);
+    if ((rc = ensure_stack_overflow(ctx, (size_t)trace_grid * kBlock))) return rc;
+    a.stack_overflow = ctx->d_stack_ovf;
+    const size_t S = ctx->wf_slots;
+    a.ray_o = ctx->wf_state; a.ray_d = ctx->wf_state + S; a.hit = ctx->wf_state + 2 * S;
+    a.path_e = ctx->wf_state + 3 * S; a.path_r = ctx->wf_state + 4 * S;
+    uint32_t *qa = ctx->wf_queues, *qb = ctx->wf_queues + S;
+    a.counts = ctx->wf_counters; a.cursors = ctx->wf_counters + (ctx->wf_iters + 2);
+    PT_HIP(ctx, hipMemsetAsync(ctx->wf_counters, 0, (ctx->wf_iters + 2) * 2 * sizeof(uint32_t), ctx->stream));
+    a.iter = 0; a.q_in = nullptr; a.q_out = qa;
+    a.refill_threshold = ctx->refill_threshold;
+    a.node_vote = ctx->node_vote;
+    hipLaunchKernelGGL(wf_generate, dim3((unsigned)item_blocks), dim3(kBlock), 0, ctx->stream, a);
+    for (size_t it = 0; it < iters; it++) {
+        a.iter = (int32_t)it;
+        a.q_in = (it & 1) ? qb : qa;
+        a.q_out = (it & 1) ? qa : qb;
+        hipLaunchKernelGGL(wf_trace, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL(wf_shade, dim3(shade_grid), dim3(kBlock), 0, ctx->stream, a);
+    }
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 // Close the statistics epoch: wait for the last render, read its counters.
 int finish_epoch(pt_context *ctx)
 {
@@ -248,8 +317,10 @@ int finish_epoch(pt_context *ctx)
     PT_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    unsigned long long h[4];
-    PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long part[kStatsShards * kStatsStride], h[4] = {0, 0, 0, 0};
+    PT_HIP(ctx, hipMemcpy(part, ctx->d_stats, sizeof part, hipMemcpyDeviceToHost));
+    for (int sh = 0; sh < kStatsShards; sh++)
+        for (int k = 0; k < 4; k++) h[k] += part[sh * kStatsStride + k];
     ctx->stats.kernel_ms = ms;
     ctx->stats.rays = h[0]; ctx->stats.nodes_visited = h[1]; ctx->stats.prims_tested = h[2]; ctx->stats.paths = h[3];
     ctx->epoch_open = false;
@@ -289,13 +360,25 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->d_work, 256)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void **)&ctx->d_stats, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_stats, kStatsShards * kStatsStride * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
     int bpc = 0;
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wf_trace, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->trace_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wf_shade, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->shade_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched_blocks_per_cu = std::max(1, bpc);
+    if (const char *env = std::getenv("PTRACE_BACKEND"))
+        ctx->backend = std::strcmp(env, "mega") == 0 ? 0 : std::strcmp(env, "mega_old") == 0 ? 2 : 1;
+    if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = std::max(1, std::min(64, std::atoi(env)));
+    if (const char *env = std::getenv("PTRACE_VOTE_NODE")) ctx->vote_node = std::max(1, std::min(64, std::atoi(env)));
+    if (const char *env = std::getenv("PTRACE_VOTE")) ctx->node_vote = std::max(1, std::min(64, std::atoi(env)));
+    if (const char *env = std::getenv("PTRACE_REFILL")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(env)));
     *out_ctx = ctx;
     return PT_OK;
 }
@@ -308,6 +391,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_nodes); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
+    free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -451,19 +535,42 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
 
     if (!ctx->epoch_open) {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, 256, ctx->stream));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, kStatsShards * kStatsStride * sizeof(unsigned long long), ctx->stream));
         PT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->epoch_open = true;
     }
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
-    int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-    int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->blocks_per_cu);
-    if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
-    a.stack_overflow = ctx->d_stack_ovf;
-    hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    PT_HIP(ctx, hipGetLastError());
+    if (ctx->backend == 1 && a.depth != 1) {
+        if ((rc = render_wavefront(ctx, a))) return rc;
+    } else {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
+        int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
+        int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * (ctx->backend == 2 ? ctx->blocks_per_cu : ctx->sched_blocks_per_cu));
+        if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
+        a.stack_overflow = ctx->d_stack_ovf;
+        a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
+        if (ctx->backend == 2) hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(path_sched_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PT_HIP(ctx, hipGetLastError());
+    }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     return PT_OK;
+}
+
+int pt_set_option(pt_context *ctx, const char *name, int value)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!name) return fail(ctx, PT_ERR_INVALID, "pt_set_option: name is NULL");
+    if (std::strcmp(name, "backend") == 0) {
+        if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: backend must be 0, 1 or 2");
+        ctx->backend = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "refill_threshold") == 0) {
+        if (value < 1 || value > 64) return fail(ctx, PT_ERR_INVALID, "pt_set_option: refill_threshold must be 1..64");
+        ctx->refill_threshold = value;
+        return PT_OK;
+    }
+    return fail(ctx, PT_ERR_INVALID, std::string("pt_set_option: unknown option ") + name);
 }
 
 int pt_sync(pt_context *ctx)

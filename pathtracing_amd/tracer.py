@@ -43,6 +43,9 @@ class PathTracer:
     def __exit__(self, *a):
         self.close()
 
+    def set_option(self, name, value):
+        self._check(self._lib.pt_set_option(self._ctx, name.encode(), int(value)), "pt_set_option")
+
     # ---- scene ------------------------------------------------------------
     def set_spheres(self, spheres):
         s = np.ascontiguousarray(spheres, np.float32).reshape(-1, 14)

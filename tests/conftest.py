@@ -18,10 +18,12 @@ def sky_small():
     return pa.procedural_sky(128, 64)
 
 
-@pytest.fixture(scope="session")
-def tracer():
-    """One libptrace context on cuda:0 for the whole GPU session."""
+@pytest.fixture(scope="session", params=["wavefront", "sched", "mega_old"])
+def tracer(request):
+    """One libptrace context on cuda:0 per backend: the wavefront stages (default) and the
+    single persistent kernel must both match the oracle."""
     import pathtracing_amd as pa
     t = pa.PathTracer(0)
+    t.set_option("backend", {"sched": 0, "wavefront": 1, "mega_old": 2}[request.param])
     yield t
     t.close()

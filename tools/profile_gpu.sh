@@ -15,8 +15,12 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
             "FETCH_SIZE" "WRITE_SIZE" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
-            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+            "GRBM_GUI_ACTIVE GRBM_TA_BUSY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_LEVEL_WAVES SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL" \
+            "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum" \
+            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout -s KILL 240 rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass failed: $pass"; tail -3 $OUT/pmc_$name.log; }
 done
-ls -R $OUT | head -50
+
+python3 $REPO/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+find $OUT -name "*.db" -delete
