@@ -182,6 +182,23 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads)
         nd.right = encode_leaf(0, 1);
         out.nodes.push_back(nd);
         out.depth = 1;
+        Bvh4Node w; std::memset(&w, 0, sizeof w);
+        for (int a = 0; a < 3; a++) w.org[a] = tmp[root].box.lo[a];
+        for (int a = 0; a < 3; a++) {
+            float ext = tmp[root].box.hi[a] - tmp[root].box.lo[a];
+            int e = -100;
+            if (ext > 0.0f && std::isfinite(ext)) {
+                (void)std::frexp(ext / 255.0f, &e);
+                if (e < -100) e = -100;
+                while (w.org[a] + 255.0f * std::ldexp(1.0f, e) < tmp[root].box.hi[a] && e < 100) e++;
+            }
+            (a == 0 ? w.ex : a == 1 ? w.ey : w.ez) = (uint8_t)(e + 127);
+            w.qlo[a][0] = 0; w.qhi[a][0] = 255;
+        }
+        w.valid = 1;
+        w.child[0] = encode_leaf(tmp[root].first, tmp[root].count);
+        out.nodes4.push_back(w);
+        out.depth4 = 1;
         return out;
     }
     out.nodes.reserve((size_t)b.next.load());
@@ -207,6 +224,66 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads)
         if (!l.count) stack.push_back({t.left, me, 0});
     }
     out.depth += 1;
+
+    // ---- collapse to four children per node: repeatedly open the inner child with the largest area
+    struct Item4 { int32_t tmp_index; int32_t parent; int slot; int depth; };
+    std::vector<Item4> st4;
+    st4.push_back({root, -1, 0, 1});
+    out.nodes4.reserve(out.nodes.size() / 2 + 1);
+    while (!st4.empty()) {
+        Item4 it = st4.back(); st4.pop_back();
+        const Tmp &t = tmp[it.tmp_index];
+        int32_t kids[4] = {t.left, t.right, -1, -1};
+        int nk = 2;
+        while (nk < 4) {
+            int best = -1; float best_area = -1.0f;
+            for (int k = 0; k < nk; k++)
+                if (tmp[kids[k]].count == 0) {
+                    float ar = box_area(tmp[kids[k]].box);
+                    if (ar > best_area) { best_area = ar; best = k; }
+                }
+            if (best < 0) break;
+            int32_t open = kids[best];
+            kids[best] = tmp[open].left;
+            kids[nk++] = tmp[open].right;
+        }
+        int32_t me = (int32_t)out.nodes4.size();
+        Bvh4Node nd; std::memset(&nd, 0, sizeof nd);
+        const Aabb &pb = t.box;
+        float cell[3];
+        uint8_t ebits[3];
+        for (int a = 0; a < 3; a++) {
+            nd.org[a] = pb.lo[a];
+            float ext = pb.hi[a] - pb.lo[a];
+            int e = -100;
+            if (ext > 0.0f && std::isfinite(ext)) {
+                (void)std::frexp(ext / 255.0f, &e);            // ext/255 = m * 2^e, m in [0.5, 1)
+                if (e < -100) e = -100;
+                while (pb.lo[a] + 255.0f * std::ldexp(1.0f, e) < pb.hi[a] && e < 100) e++;
+            }
+            cell[a] = std::ldexp(1.0f, e);
+            ebits[a] = (uint8_t)(e + 127);
+        }
+        nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
+        for (int k = 0; k < nk; k++) {
+            const Tmp &c = tmp[kids[k]];
+            nd.valid |= (uint8_t)(1u << k);
+            for (int a = 0; a < 3; a++) {
+                float fl = std::floor((c.box.lo[a] - pb.lo[a]) / cell[a]);
+                float fh = std::ceil((c.box.hi[a] - pb.lo[a]) / cell[a]);
+                int ql = (int)std::min(255.0f, std::max(0.0f, fl)), qh = (int)std::min(255.0f, std::max(0.0f, fh));
+                while (ql > 0 && pb.lo[a] + (float)ql * cell[a] > c.box.lo[a]) ql--;      // outward rounding survives
+                while (qh < 255 && pb.lo[a] + (float)qh * cell[a] < c.box.hi[a]) qh++;    // the float arithmetic
+                nd.qlo[a][k] = (uint8_t)ql; nd.qhi[a][k] = (uint8_t)qh;
+            }
+            nd.child[k] = c.count ? encode_leaf(c.first, c.count) : 0;
+        }
+        out.nodes4.push_back(nd);
+        if (it.parent >= 0) out.nodes4[it.parent].child[it.slot] = me;
+        out.depth4 = std::max(out.depth4, it.depth);
+        for (int k = nk - 1; k >= 0; k--)
+            if (!tmp[kids[k]].count) st4.push_back({kids[k], me, k, it.depth + 1});
+    }
     return out;
 }
 

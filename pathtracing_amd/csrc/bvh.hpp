@@ -31,8 +31,27 @@ struct alignas(64) BvhNode {
 constexpr int kMaxLeafPrims = 8;   // what the 3-bit count field can hold
 constexpr int kMaxDepth = 60;      // traversal stack capacity bounds the depth
 
+// Wide device node, 64 bytes (56 used): four children whose boxes are quantised to 8 bits per plane
+// on a per-node grid (origin + power-of-two cell per axis), rounded outwards so a quantised box
+// always contains the exact one.
+//   q0 = (org.x, org.y, org.z, ex | ey << 8 | ez << 16 | valid << 24)    cell = 2^(e - 127)
+//   q1 = child[0..3]            same encoding as BvhNode's links
+//   q2 = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   one byte per child
+//   q3 = (qhi.y[4], qhi.z[4], -, -)
+struct alignas(64) Bvh4Node {
+    float org[3];
+    uint8_t ex, ey, ez, valid;
+    int32_t child[4];
+    uint8_t qlo[3][4];
+    uint8_t qhi[3][4];
+    uint32_t pad[2];
+};
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node layout");
+
 struct BvhResult {
     std::vector<BvhNode> nodes;       // nodes[0] is the root (always an inner node) unless empty
+    std::vector<Bvh4Node> nodes4;     // the same tree collapsed to four children per node; nodes4[0] is the root
+    int depth4 = 0;
     std::vector<uint32_t> order;      // order[k] = input primitive index of reordered slot k
     int depth = 0;
 };

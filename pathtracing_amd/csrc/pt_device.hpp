@@ -17,7 +17,8 @@ namespace ptrace {
 typedef pt_f3 f3;
 
 struct SceneDev {
-    const float4 *nodes;       // 4 x float4 per BvhNode
+    const float4 *nodes;       // 4 x float4 per BvhNode (two children per node)
+    const uint4 *nodes4;       // 4 x uint4 per Bvh4Node (four children, 8-bit boxes); see bvh.hpp
     const float4 *prims;       // 3 x float4 per primitive record, BVH order
     const float4 *sphere_mat;  // 4 x float4 per sphere: (pos,r) (albedo,smoothness) (specular,0) (emission,0)
     const float4 *sky;         // RGBA32F texels, row 0 at v = 0
@@ -67,7 +68,9 @@ struct RenderArgs {
 
 constexpr int kBlock = 256;            // 4 waves
 constexpr int kStackLds = 16;          // traversal stack entries kept in LDS per lane
-constexpr int kStackOverflow = 48;     // further entries in a global buffer (depth bound: bvh.hpp kMaxDepth)
+constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 96 >= the deepest stack:
+                                       // kMaxDepth (60) pushes for two-child nodes, 3 * ceil(60 / 2) for four-child nodes
+constexpr int kDoneNode = (int)0x80000000;   // traversal state "stack empty: ray finished"
 
 __device__ __forceinline__ float as_f(int32_t i) { return __int_as_float(i); }
 __device__ __forceinline__ int32_t as_i(float f) { return __float_as_int(f); }
@@ -137,62 +140,129 @@ __device__ __forceinline__ void intersect_prim(const float4 *prims, uint32_t rec
     }
 }
 
+// Reciprocal direction for the slab tests, with |d| clamped away from zero: an infinite reciprocal
+// would turn lo*inv - o*inv into inf - inf.  Moving an axis-parallel ray by 1e-18 per unit length is
+// far inside the padding of the boxes.
+struct RaySlabs { float ix, iy, iz, ox, oy, oz; };
+__device__ __forceinline__ RaySlabs ray_slabs(f3 o, f3 d)
+{
+    const float kTiny = 1e-18f;
+    RaySlabs r;
+    r.ix = 1.0f / (pt_abs(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x);
+    r.iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
+    r.iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
+    r.ox = -o.x * r.ix; r.oy = -o.y * r.iy; r.oz = -o.z * r.iz;
+    return r;
+}
+
+// One inner node: test the children, push the ones to visit later (farther ones deeper), return
+// the nearest one entered - or the next stacked node, or kDoneNode.  The slab tests use a widened
+// exit distance and non-strict comparisons: they may enter a box needlessly, never skip one.
+template <int WIDE>
+__device__ __forceinline__ int32_t node_step(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
+                                             const Stack &st, int &sp);
+
+template <>
+__device__ __forceinline__ int32_t node_step<2>(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
+                                                const Stack &st, int &sp)
+{
+    const float4 *q = sc.nodes + (size_t)node * 4;
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    float l0x = __builtin_fmaf(q0.x, r.ix, r.ox), l1x = __builtin_fmaf(q1.x, r.ix, r.ox);
+    float l0y = __builtin_fmaf(q0.y, r.iy, r.oy), l1y = __builtin_fmaf(q1.y, r.iy, r.oy);
+    float l0z = __builtin_fmaf(q0.z, r.iz, r.oz), l1z = __builtin_fmaf(q1.z, r.iz, r.oz);
+    float r0x = __builtin_fmaf(q2.x, r.ix, r.ox), r1x = __builtin_fmaf(q3.x, r.ix, r.ox);
+    float r0y = __builtin_fmaf(q2.y, r.iy, r.oy), r1y = __builtin_fmaf(q3.y, r.iy, r.oy);
+    float r0z = __builtin_fmaf(q2.z, r.iz, r.oz), r1z = __builtin_fmaf(q3.z, r.iz, r.oz);
+    float ln = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), 0.0f));
+    float lf = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fmaxf(l0z, l1z));
+    float rn = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), 0.0f));
+    float rf = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fmaxf(r0z, r1z));
+    bool hl = ln <= lf * 1.000002f && ln <= tbest;
+    bool hr = rn <= rf * 1.000002f && rn <= tbest;
+    int32_t cl = as_i(q0.w), cr = as_i(q1.w);
+    if (hl && hr) {
+        bool left_first = ln <= rn;
+        stack_push(st, sp, left_first ? cr : cl);
+        return left_first ? cl : cr;
+    }
+    if (hl) return cl;
+    if (hr) return cr;
+    return sp ? stack_pop(st, sp) : kDoneNode;
+}
+
+__device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+
+template <>
+__device__ __forceinline__ int32_t node_step<4>(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
+                                                const Stack &st, int &sp)
+{
+    const uint4 *q = sc.nodes4 + (size_t)node * 4;
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const uint2 q3 = *reinterpret_cast<const uint2 *>(q + 3);
+    const uint32_t meta = q0.w;
+    // plane position along the ray: ((org + k * cell) - o) * inv = k * (cell * inv) + (org - o) * inv
+    const float sx = __uint_as_float((meta & 0xffu) << 23) * r.ix;
+    const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * r.iy;
+    const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * r.iz;
+    const float bx = __builtin_fmaf(__uint_as_float(q0.x), r.ix, r.ox);
+    const float by = __builtin_fmaf(__uint_as_float(q0.y), r.iy, r.oy);
+    const float bz = __builtin_fmaf(__uint_as_float(q0.z), r.iz, r.oz);
+    // per axis: the plane the ray meets first is the low one when it travels in +axis, else the high one
+    const uint32_t nx4 = r.ix >= 0.0f ? q2.x : q2.w, fx4 = r.ix >= 0.0f ? q2.w : q2.x;
+    const uint32_t ny4 = r.iy >= 0.0f ? q2.y : q3.x, fy4 = r.iy >= 0.0f ? q3.x : q2.y;
+    const uint32_t nz4 = r.iz >= 0.0f ? q2.z : q3.y, fz4 = r.iz >= 0.0f ? q3.y : q2.z;
+    uint32_t key[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float nx = __builtin_fmaf(ubyte_f(nx4, c), sx, bx), fx = __builtin_fmaf(ubyte_f(fx4, c), sx, bx);
+        float ny = __builtin_fmaf(ubyte_f(ny4, c), sy, by), fy = __builtin_fmaf(ubyte_f(fy4, c), sy, by);
+        float nz = __builtin_fmaf(ubyte_f(nz4, c), sz, bz), fz = __builtin_fmaf(ubyte_f(fz4, c), sz, bz);
+        float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+        float tf = fminf(fminf(fx, fy), fz);
+        bool hit = tn <= tf * 1.000002f && tn <= tbest && ((meta >> (24 + c)) & 1u);
+        // entry distance (>= 0, so its bits order like an unsigned) with the child slot in the low bits
+        key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
+    }
+    // sorting network, ascending: nearest child first, misses last
+#define PT_CSWAP(i, j) { uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+    auto child_of = [&](uint32_t k) -> int32_t {
+        uint32_t s = k & 3u;
+        return (int32_t)(s == 0 ? q1.x : s == 1 ? q1.y : s == 2 ? q1.z : q1.w);
+    };
+    if (key[0] == 0xffffffffu) return sp ? stack_pop(st, sp) : kDoneNode;
+    if (key[3] != 0xffffffffu) stack_push(st, sp, child_of(key[3]));
+    if (key[2] != 0xffffffffu) stack_push(st, sp, child_of(key[2]));
+    if (key[1] != 0xffffffffu) stack_push(st, sp, child_of(key[1]));
+    return child_of(key[0]);
+}
+
+// One leaf: every primitive of it against the ray, then the next stacked node (or kDoneNode).
+__device__ __forceinline__ int32_t leaf_step(const SceneDev &sc, int32_t node, f3 o, f3 d, float &tbest, int32_t &idbest,
+                                             uint32_t &recbest, const Stack &st, int &sp, uint32_t &n_prims)
+{
+    uint32_t enc = (uint32_t)~node;
+    uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+    for (uint32_t k = 0; k < count; k++) intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
+    n_prims += count;
+    return sp ? stack_pop(st, sp) : kDoneNode;
+}
+
 // Closest hit over spheres and triangles through the BVH.  tbest/idbest come in
 // holding the ground-plane result (or +inf / -1).
+template <int WIDE>
 __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &tbest, int32_t &idbest,
                                          uint32_t &recbest, const Stack &st, uint32_t &n_nodes, uint32_t &n_prims)
 {
     if (sc.n_nodes == 0) return;
-    // Slab tests use 1/d with |d| clamped away from zero: an infinite reciprocal would turn
-    // lo*inv - o*inv into inf - inf.  Moving an axis-parallel ray by 1e-18 per unit length is
-    // far inside the padding of the boxes.
-    const float kTiny = 1e-18f;
-    const float ix = 1.0f / (pt_abs(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x);
-    const float iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
-    const float iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
-    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    const RaySlabs r = ray_slabs(o, d);
     int sp = 0;
     int32_t node = 0;
-    for (;;) {
-        while (node >= 0) {
-            const float4 *q = sc.nodes + (size_t)node * 4;
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            n_nodes++;
-            float l0x = __builtin_fmaf(q0.x, ix, ox), l1x = __builtin_fmaf(q1.x, ix, ox);
-            float l0y = __builtin_fmaf(q0.y, iy, oy), l1y = __builtin_fmaf(q1.y, iy, oy);
-            float l0z = __builtin_fmaf(q0.z, iz, oz), l1z = __builtin_fmaf(q1.z, iz, oz);
-            float r0x = __builtin_fmaf(q2.x, ix, ox), r1x = __builtin_fmaf(q3.x, ix, ox);
-            float r0y = __builtin_fmaf(q2.y, iy, oy), r1y = __builtin_fmaf(q3.y, iy, oy);
-            float r0z = __builtin_fmaf(q2.z, iz, oz), r1z = __builtin_fmaf(q3.z, iz, oz);
-            float ln = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), 0.0f));
-            float lf = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fmaxf(l0z, l1z));
-            float rn = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), 0.0f));
-            float rf = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fmaxf(r0z, r1z));
-            // widened exit distance + non-strict comparisons: never cull a box the exact test would enter
-            bool hl = ln <= lf * 1.000002f && ln <= tbest;
-            bool hr = rn <= rf * 1.000002f && rn <= tbest;
-            int32_t cl = as_i(q0.w), cr = as_i(q1.w);
-            if (hl && hr) {
-                bool left_first = ln <= rn;
-                stack_push(st, sp, left_first ? cr : cl);
-                node = left_first ? cl : cr;
-            } else if (hl) {
-                node = cl;
-            } else if (hr) {
-                node = cr;
-            } else {
-                if (sp == 0) return;
-                node = stack_pop(st, sp);
-            }
-        }
-        uint32_t enc = (uint32_t)~node;
-        uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-            intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
-        }
-        n_prims += count;
-        if (sp == 0) return;
-        node = stack_pop(st, sp);
+    while (node != kDoneNode) {
+        if (node >= 0) { node = node_step<WIDE>(sc, node, r, tbest, st, sp); n_nodes++; }
+        else node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, n_prims);
     }
 }
 
@@ -392,7 +462,8 @@ __device__ __forceinline__ void accumulate_pixel(const RenderArgs &a, size_t p, 
 // Counter totals go to one of kStatsShards copies (picked by block id) so that thousands of waves
 // finishing together do not queue on one address; the host adds the copies up.
 constexpr int kStatsShards = 64;
-constexpr int kStatsStride = 8;   // u64 words per shard: rays, nodes, prims, paths, (unused)
+constexpr int kStatsStride = 16;  // u64 words per shard: rays, nodes, prims, paths; with PT_PROFILE_PHASES also
+                                  // [4..9] = rounds and active lanes of the shade, node and leaf phases
 __device__ __forceinline__ void stats_add(unsigned long long *stats, int which, uint32_t v, int lane)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -401,130 +472,17 @@ __device__ __forceinline__ void stats_add(unsigned long long *stats, int which, 
 
 // --------------------------------------------------------------- path kernel
 //
-// Persistent kernel: the grid is sized to fill the chip once; every lane owns
-// one pixel at a time and pulls the next one from a global counter as soon as
-// its pixel is finished, so lanes whose paths ended early (sky, roulette) are
-// refilled between bounces instead of idling until the longest path of the
-// wave ends.  A pixel's samples are taken in order by one lane because the
-// shader's RNG counter runs on across samples (SH:839: _Seed is never reset).
+// Persistent kernel: the grid is sized to fill the chip once; every lane owns one pixel at a time
+// and pulls the next one from a global counter as soon as its pixel is finished.  A pixel's samples
+// are taken in order by one lane because the shader's RNG counter runs on across samples (SH:839:
+// _Seed is never reset).  Work item i -> 8x8 pixel block i/64 of the tile rectangle (row-major
+// blocks), pixel i%64 inside it, so the 64 items a fresh wave draws are one block.
 //
-// Work item i -> 8x8 pixel block i/64 of the tile rectangle (row-major blocks),
-// pixel i%64 inside it, so the 64 items a fresh wave draws are one block.
-__global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
-{
-    __shared__ uint32_t lds_stack[kStackLds * kBlock];
-    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + (blockIdx.x * kBlock + threadIdx.x), gridDim.x * kBlock};
-    const int lane = threadIdx.x & 63;
-
-    int32_t pix_x = -1, pix_y = 0;   // pix_x < 0: lane has no pixel
-    bool dead = false;                // no work left for this lane
-    int32_t sample = 0, bounce = 0;
-    bool primary_miss = false;
-    Rng rs = {0.0f, 0.0f};
-    f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1), energy = pt_make3(0, 0, 0), result = pt_make3(0, 0, 0);
-    f3 cam_o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
-    float alpha_dist = 0.0f;
-    int32_t primary_id = -1;
-    const float fspp = (float)a.spp;
-    uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_paths = 0;
-
-    for (;;) {
-        // ---- refill idle lanes with new pixels: one wave-aggregated bump of the global counter for
-        //      exactly the lanes that need one (finest-grained balancing; coarser per-wave chunks
-        //      measured 2x slower because the last chunks serialise)
-        bool need = pix_x < 0 && !dead;
-        unsigned long long m = __ballot(need);
-        if (m) {
-            int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(a.work_counter, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (need) {
-                uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (item >= a.total_items) {
-                    dead = true;
-                } else {
-                    int x, y;
-                    if (item_pixel(a, item, x, y)) {
-                        pix_x = x; pix_y = y;
-                        sample = 0; bounce = 0;
-                        rs.seed = a.seed;
-                        rs.dotp = pixel_dot(x, y);
-                        result = pt_make3(0, 0, 0);
-                        energy = pt_make3(1, 1, 1);
-                        camera_ray(a, x, y, o, d);
-                        c_paths++;
-                    }
-                }
-            }
-        }
-        if (__ballot(!dead) == 0ull) break;
-
-        const bool active = pix_x >= 0;
-        if (active) {
-            // ---- Trace (SH:262-285)
-            float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
-            intersect_ground_plane(o, d, t, id);
-            traverse(a.sc, o, d, t, id, rec, st, c_nodes, c_prims);
-            c_rays++;
-
-            if (a.depth == 1) {                                   // SH:799-809
-                size_t p = (size_t)pix_y * a.W + pix_x;
-                float dis = t / 16.0f;
-                a.result[p] = make_float4(dis, dis, dis, dis);
-                if (a.hit_ids) a.hit_ids[p] = id;
-                pix_x = -1;
-            } else {
-                // ---- Shade; energy is read before it is updated (SH:866)
-                f3 e = energy, hit_pos;
-                f3 s = shade(a.sc, rs, o, d, energy, t, id, rec, hit_pos);
-                result.x += e.x * s.x / fspp;
-                result.y += e.y * s.y / fspp;
-                result.z += e.z * s.z / fspp;
-                bool path_done;
-                if (bounce == 0) {
-                    primary_id = id;
-                    primary_miss = !(t < PT_INF);
-                    alpha_dist = pt_length3(pt_sub3(hit_pos, cam_o));  // SH:860, SH:935
-                    // The shader traces once more even when the energy is already zero (SH:867-870).
-                    // After a primary miss that re-trace sees the same ray, draws no random number and
-                    // adds 0 * sky: it is skipped.  Any other zero-energy case is traced, because its
-                    // Shade() advances the RNG counter that later samples of the pixel continue from.
-                    path_done = primary_miss || a.maxb <= 1;
-                } else {
-                    path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
-                }
-                bounce++;
-                if (path_done) {
-                    sample++;
-                    if (sample < a.spp) {                          // next sample of the same pixel, SH:839
-                        bounce = 0;
-                        energy = pt_make3(1, 1, 1);
-                        camera_ray(a, pix_x, pix_y, o, d);
-                        c_paths++;
-                    } else {                                       // SH:933-936
-                        size_t p = (size_t)pix_y * a.W + pix_x;
-                        float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
-                        a.result[p] = fresh;
-                        if (a.hit_ids) a.hit_ids[p] = primary_id;
-                        accumulate_pixel(a, p, fresh);
-                        pix_x = -1;
-                    }
-                }
-            }
-        }
-    }
-
-    stats_add(a.stats, 0, c_rays, lane);
-    stats_add(a.stats, 1, c_nodes, lane);
-    stats_add(a.stats, 2, c_prims, lane);
-    stats_add(a.stats, 3, c_paths, lane);
-}
-
-// ------------------------------------------------- scheduled path kernel
+// After a primary miss the shader traces the unchanged ray once more with zero energy (SH:867-870);
+// that re-trace draws no random number and adds 0 * sky, so it is skipped.  Every other zero-energy
+// case is traced, because its Shade() advances the RNG counter later samples of the pixel start from.
 //
-// The same persistent one-pixel-per-lane path tracer as path_kernel, but the wave no longer
-// walks "trace everyone, then shade everyone".  Every lane is in one of four states -
+// The wave does not walk "trace everyone, then shade everyone".  Every lane is in one of four states -
 // holding an inner BVH node, holding a leaf, holding a finished ray that waits for Shade(),
 // or idle - and each round the wave runs the ONE phase that most lanes can take part in:
 //
@@ -536,8 +494,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(const RenderArgs a)
 // A lane whose ray ends early therefore waits only until enough other lanes have ended too,
 // not until the longest ray of the wave is done, and the expensive shading code runs with
 // many lanes active.  Per-pixel arithmetic and its order are unchanged.
-constexpr int kDoneNodeSm = (int)0x80000000;
-
+template <int WIDE>
 __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
 {
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
@@ -550,27 +507,33 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
     int32_t sample = 0, bounce = 0;
     float seed = 0.0f;
     f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1), energy = pt_make3(0, 0, 0), result = pt_make3(0, 0, 0);
-    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+    RaySlabs rsl = {0, 0, 0, 0, 0, 0};
     const f3 cam_o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
     float alpha_dist = 0.0f;
     int32_t primary_id = -1;
     float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
-    int32_t node = kDoneNodeSm; int sp = 0;   // node == kDoneNodeSm with a pixel: ray finished, waits for Shade()
+    int32_t node = kDoneNode; int sp = 0;   // node == kDoneNode with a pixel: ray finished, waits for Shade()
     const float fspp = (float)a.spp;
     uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_paths = 0;
+#ifdef PT_PROFILE_PHASES
+    uint32_t ph_rounds[3] = {0, 0, 0}, ph_lanes[3] = {0, 0, 0};   // wave-uniform
+#endif
 
     for (;;) {
         const bool has_pixel = pix_x >= 0;
         const bool inner = has_pixel && node >= 0;
-        const bool leaf = has_pixel && node < 0 && node != kDoneNodeSm;
-        const bool waiting = (has_pixel && node == kDoneNodeSm) || (!has_pixel && !dead);
+        const bool leaf = has_pixel && node < 0 && node != kDoneNode;
+        const bool waiting = (has_pixel && node == kDoneNode) || (!has_pixel && !dead);
         const int n_inner = __popcll(__ballot(inner)), n_leaf = __popcll(__ballot(leaf)), n_wait = __popcll(__ballot(waiting));
         if (n_inner + n_leaf + n_wait == 0) break;
 
         if (n_wait >= a.vote_shade || n_inner + n_leaf == 0) {
             // ================= shade phase =================
+#ifdef PT_PROFILE_PHASES
+            ph_rounds[0]++; ph_lanes[0] += n_wait;
+#endif
             bool new_ray = false;
-            if (has_pixel && node == kDoneNodeSm) {
+            if (has_pixel && node == kDoneNode) {
                 if (a.depth == 1) {                                   // SH:799-809
                     size_t p = (size_t)pix_y * a.W + pix_x;
                     float dis = tbest / 16.0f;
@@ -589,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
                     if (bounce == 0) {
                         primary_id = idbest;
                         alpha_dist = pt_length3(pt_sub3(hit_pos, cam_o));
-                        path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see path_kernel
+                        path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see the note above
                     } else {
                         path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
                     }
@@ -645,13 +608,9 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
             if (new_ray) {
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
-                const float kTiny = 1e-18f;   // see traverse()
-                ix = 1.0f / (pt_abs(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x);
-                iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
-                iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
-                ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
+                rsl = ray_slabs(o, d);
                 sp = 0;
-                node = sc.n_nodes ? 0 : kDoneNodeSm;
+                node = sc.n_nodes ? 0 : kDoneNode;
                 c_rays++;
             }
             continue;
@@ -659,57 +618,47 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
 
         if (n_inner >= a.vote_node || n_leaf == 0) {
             // ================= node phase =================
-            if (inner) {
-                const float4 *q = sc.nodes + (size_t)node * 4;
-                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                c_nodes++;
-                float l0x = __builtin_fmaf(q0.x, ix, ox), l1x = __builtin_fmaf(q1.x, ix, ox);
-                float l0y = __builtin_fmaf(q0.y, iy, oy), l1y = __builtin_fmaf(q1.y, iy, oy);
-                float l0z = __builtin_fmaf(q0.z, iz, oz), l1z = __builtin_fmaf(q1.z, iz, oz);
-                float r0x = __builtin_fmaf(q2.x, ix, ox), r1x = __builtin_fmaf(q3.x, ix, ox);
-                float r0y = __builtin_fmaf(q2.y, iy, oy), r1y = __builtin_fmaf(q3.y, iy, oy);
-                float r0z = __builtin_fmaf(q2.z, iz, oz), r1z = __builtin_fmaf(q3.z, iz, oz);
-                float ln = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), 0.0f));
-                float lf = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fmaxf(l0z, l1z));
-                float rn = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), 0.0f));
-                float rf = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fmaxf(r0z, r1z));
-                bool hl = ln <= lf * 1.000002f && ln <= tbest;
-                bool hr = rn <= rf * 1.000002f && rn <= tbest;
-                int32_t cl = as_i(q0.w), cr = as_i(q1.w);
-                if (hl && hr) {
-                    bool left_first = ln <= rn;
-                    stack_push(st, sp, left_first ? cr : cl);
-                    node = left_first ? cl : cr;
-                } else if (hl) {
-                    node = cl;
-                } else if (hr) {
-                    node = cr;
-                } else {
-                    node = sp ? stack_pop(st, sp) : kDoneNodeSm;
-                }
+#ifdef PT_PROFILE_PHASES
+            ph_rounds[1]++; ph_lanes[1] += n_inner;
+#endif
+            // keep stepping while enough lanes hold an inner node; the other lanes' states cannot change
+            // meanwhile, so only that one count is re-evaluated
+            for (;;) {
+                const bool in = pix_x >= 0 && node >= 0;
+                if (in) { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); c_nodes++; }
+                const int still = __popcll(__ballot(pix_x >= 0 && node >= 0));
+#ifdef PT_PROFILE_PHASES
+                if (still >= a.vote_node) { ph_rounds[1]++; ph_lanes[1] += still; }
+#endif
+                if (still < a.vote_node) break;
             }
             continue;
         }
 
         // ================= leaf phase =================
-        if (leaf) {
-            uint32_t enc = (uint32_t)~node;
-            uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
-            c_prims += count;
-            node = sp ? stack_pop(st, sp) : kDoneNodeSm;
-        }
+#ifdef PT_PROFILE_PHASES
+        ph_rounds[2]++; ph_lanes[2] += n_leaf;
+#endif
+        if (leaf) node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, c_prims);
     }
 
     stats_add(a.stats, 0, c_rays, lane);
     stats_add(a.stats, 1, c_nodes, lane);
     stats_add(a.stats, 2, c_prims, lane);
     stats_add(a.stats, 3, c_paths, lane);
+#ifdef PT_PROFILE_PHASES
+    if (lane == 0 && a.stats)
+        for (int k = 0; k < 3; k++) {
+            atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 4 + 2 * k], (unsigned long long)ph_rounds[k]);
+            atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 5 + 2 * k], (unsigned long long)ph_lanes[k]);
+        }
+#endif
 }
 
 // ------------------------------------------------------- ray-query kernels
 
 // One thread per caller-supplied ray; BVH traversal.
+template <int WIDE>
 __global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uint32_t *stack_overflow, const float *od, int n,
                                                                  int32_t *ids, float *ts)
 {
@@ -721,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uin
     f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);
     float t = PT_INF; int32_t id = -1; uint32_t rec = 0, cn = 0, cp = 0;
     intersect_ground_plane(o, d, t, id);
-    traverse(sc, o, d, t, id, rec, st, cn, cp);
+    traverse<WIDE>(sc, o, d, t, id, rec, st, cn, cp);
     ids[i] = id; ts[i] = t;
 }
 

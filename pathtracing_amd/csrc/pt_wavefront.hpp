@@ -19,8 +19,6 @@
 
 namespace ptrace {
 
-constexpr int kDoneNode = (int)0x80000000;   // traversal state "no ray / ray finished"
-
 __device__ __forceinline__ void wave_append(uint32_t *queue, uint32_t *count, bool want, uint32_t value, int lane)
 {
     unsigned long long m = __ballot(want);
@@ -52,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(const RenderArgs a)
 
 // Persistent traversal.  Each wave owns a range [q_next, q_end) of queue indices claimed from the
 // global cursor in chunks; idle lanes are refilled from it at the top of every round.
+template <int WIDE>
 __global__ __launch_bounds__(kBlock) void wf_trace(const RenderArgs a)
 {
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const RenderArgs a)
     bool exhausted = false;             // wave-uniform: the global queue has no more chunks
     int32_t slot = -1;
     f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1);
-    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0;
+    RaySlabs rsl = {0, 0, 0, 0, 0, 0};
     float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
     int32_t node = kDoneNode; int sp = 0;
     uint32_t c_rays = 0, c_nodes = 0, c_prims = 0;
@@ -94,11 +93,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const RenderArgs a)
                 o = xyz(ro); d = xyz(rd);
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
-                const float kTiny = 1e-18f;   // see traverse()
-                ix = 1.0f / (pt_abs(d.x) < kTiny ? __builtin_copysignf(kTiny, d.x) : d.x);
-                iy = 1.0f / (pt_abs(d.y) < kTiny ? __builtin_copysignf(kTiny, d.y) : d.y);
-                iz = 1.0f / (pt_abs(d.z) < kTiny ? __builtin_copysignf(kTiny, d.z) : d.z);
-                ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
+                rsl = ray_slabs(o, d);
                 sp = 0;
                 node = sc.n_nodes ? 0 : kDoneNode;
                 c_rays++;
@@ -114,42 +109,11 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const RenderArgs a)
             // leave when no lane holds an inner node, or when only a few do while others wait with a leaf
             if (n_inner == 0 || (n_inner < a.node_vote && __ballot(node < 0 && node != kDoneNode) != 0ull)) break;
             if (!inner) continue;
-            const float4 *q = sc.nodes + (size_t)node * 4;
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            node = node_step<WIDE>(sc, node, rsl, tbest, st, sp);
             c_nodes++;
-            float l0x = __builtin_fmaf(q0.x, ix, ox), l1x = __builtin_fmaf(q1.x, ix, ox);
-            float l0y = __builtin_fmaf(q0.y, iy, oy), l1y = __builtin_fmaf(q1.y, iy, oy);
-            float l0z = __builtin_fmaf(q0.z, iz, oz), l1z = __builtin_fmaf(q1.z, iz, oz);
-            float r0x = __builtin_fmaf(q2.x, ix, ox), r1x = __builtin_fmaf(q3.x, ix, ox);
-            float r0y = __builtin_fmaf(q2.y, iy, oy), r1y = __builtin_fmaf(q3.y, iy, oy);
-            float r0z = __builtin_fmaf(q2.z, iz, oz), r1z = __builtin_fmaf(q3.z, iz, oz);
-            float ln = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), 0.0f));
-            float lf = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fmaxf(l0z, l1z));
-            float rn = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), 0.0f));
-            float rf = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fmaxf(r0z, r1z));
-            bool hl = ln <= lf * 1.000002f && ln <= tbest;
-            bool hr = rn <= rf * 1.000002f && rn <= tbest;
-            int32_t cl = as_i(q0.w), cr = as_i(q1.w);
-            if (hl && hr) {
-                bool left_first = ln <= rn;
-                stack_push(st, sp, left_first ? cr : cl);
-                node = left_first ? cl : cr;
-            } else if (hl) {
-                node = cl;
-            } else if (hr) {
-                node = cr;
-            } else {
-                node = sp ? stack_pop(st, sp) : kDoneNode;
-            }
         }
         // ---- one leaf
-        if (node < 0 && node != kDoneNode) {
-            uint32_t enc = (uint32_t)~node;
-            uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
-            c_prims += count;
-            node = sp ? stack_pop(st, sp) : kDoneNode;
-        }
+        if (node < 0 && node != kDoneNode) node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, c_prims);
         // ---- finished rays
         if (slot >= 0 && node == kDoneNode) {
             a.hit[slot] = make_float4(tbest, as_f(idbest), as_f((int32_t)recbest), 0.0f);
@@ -199,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(const RenderArgs a)
             if (bounce == 0) {
                 primary_id = id;
                 alpha_dist = pt_length3(pt_sub3(hit_pos, cam_o));
-                path_done = !(t < PT_INF) || a.maxb <= 1;        // see path_kernel for the primary-miss case
+                path_done = !(t < PT_INF) || a.maxb <= 1;        // primary miss: see the path kernel's note
             } else {
                 path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || (int)bounce + 1 >= a.maxb;
             }

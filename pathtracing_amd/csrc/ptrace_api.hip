@@ -33,8 +33,10 @@ struct pt_context {
     bool scene_dirty = true;
 
     // device scene
+    uint4 *d_nodes4 = nullptr;
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_sphere_mat = nullptr, *d_sky = nullptr;
     uint32_t *d_by_id = nullptr;
+    int n_nodes4 = 0, bvh_width = 4;
     int n_nodes = 0, n_prims = 0, n_spheres = 0, sky_w = 0, sky_h = 0;
 
     // targets
@@ -51,14 +53,14 @@ struct pt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool epoch_open = false;  // renders issued since the last pt_get_stats
     PtStats stats{};
-    int num_cus = 0, blocks_per_cu = 0;
+    int num_cus = 0;
 
     // wavefront pipeline
     int refill_threshold = 32;
     int node_vote = 8;
-    int vote_shade = 16, vote_node = 8;
+    int vote_shade = 36, vote_node = 16;
     int sched_blocks_per_cu = 0;
-    int backend = 1;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
+    int backend = 0;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
     int trace_blocks_per_cu = 0, shade_blocks_per_cu = 0;
     float4 *wf_state = nullptr;            // 5 float4 arrays of wf_slots entries
     uint32_t *wf_queues = nullptr;         // 2 queues of wf_slots entries
@@ -205,15 +207,17 @@ int rebuild_scene(pt_context *ctx)
     }
     int rc;
     if ((rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;
+    if ((rc = upload(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
+    ctx->n_nodes4 = (int)bvh.nodes4.size();
     if ((rc = upload(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
     if ((rc = upload(ctx, ctx->d_by_id, by_id.data(), by_id.size() * sizeof(uint32_t)))) return rc;
     if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
     ctx->n_nodes = (int)bvh.nodes.size();
     ctx->n_prims = (int)nP;
     ctx->n_spheres = nS;
-    ctx->stats.bvh_nodes = ctx->n_nodes;
+    ctx->stats.bvh_nodes = ctx->bvh_width == 4 ? ctx->n_nodes4 : ctx->n_nodes;
     ctx->stats.bvh_prims = ctx->n_prims;
-    ctx->stats.bvh_depth = bvh.depth;
+    ctx->stats.bvh_depth = ctx->bvh_width == 4 ? bvh.depth4 : bvh.depth;
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->scene_dirty = false;
@@ -223,7 +227,7 @@ int rebuild_scene(pt_context *ctx)
 SceneDev scene_dev(const pt_context *ctx)
 {
     SceneDev sc;
-    sc.nodes = ctx->d_nodes; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
+    sc.nodes = ctx->d_nodes; sc.nodes4 = ctx->d_nodes4; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
     sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
     sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres;
     return sc;
@@ -303,7 +307,8 @@ int render_wavefront(pt_context *ctx, RenderArgs &a)
         a.iter = (int32_t)it;
         a.q_in = (it & 1) ? qb : qa;
         a.q_out = (it & 1) ? qa : qb;
-        hipLaunchKernelGGL(wf_trace, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
+        if (ctx->bvh_width == 4) hipLaunchKernelGGL(wf_trace<4>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(wf_trace<2>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
         hipLaunchKernelGGL(wf_shade, dim3(shade_grid), dim3(kBlock), 0, ctx->stream, a);
     }
     PT_HIP(ctx, hipGetLastError());
@@ -321,6 +326,16 @@ int finish_epoch(pt_context *ctx)
     PT_HIP(ctx, hipMemcpy(part, ctx->d_stats, sizeof part, hipMemcpyDeviceToHost));
     for (int sh = 0; sh < kStatsShards; sh++)
         for (int k = 0; k < 4; k++) h[k] += part[sh * kStatsStride + k];
+#ifdef PT_PROFILE_PHASES
+    {
+        unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+        for (int sh = 0; sh < kStatsShards; sh++)
+            for (int k = 0; k < 6; k++) ph[k] += part[sh * kStatsStride + 4 + k];
+        const char *names[3] = {"shade", "node", "leaf"};
+        for (int k = 0; k < 3; k++)
+            std::fprintf(stderr, "phase %-5s rounds %12llu  lanes/round %6.2f\n", names[k], ph[2 * k], ph[2 * k] ? (double)ph[2 * k + 1] / (double)ph[2 * k] : 0.0);
+    }
+#endif
     ctx->stats.kernel_ms = ms;
     ctx->stats.rays = h[0]; ctx->stats.nodes_visited = h[1]; ctx->stats.prims_tested = h[2]; ctx->stats.paths = h[3];
     ctx->epoch_open = false;
@@ -365,16 +380,15 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
     int bpc = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
-    ctx->blocks_per_cu = std::max(1, bpc);
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wf_trace, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wf_trace<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->trace_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wf_shade, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->shade_blocks_per_cu = std::max(1, bpc);
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched_blocks_per_cu = std::max(1, bpc);
     if (const char *env = std::getenv("PTRACE_BACKEND"))
-        ctx->backend = std::strcmp(env, "mega") == 0 ? 0 : std::strcmp(env, "mega_old") == 0 ? 2 : 1;
+        ctx->backend = std::strcmp(env, "mega") == 0 ? 0 : 1;
+    if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : 4;
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_NODE")) ctx->vote_node = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE")) ctx->node_vote = std::max(1, std::min(64, std::atoi(env)));
@@ -388,7 +402,7 @@ void pt_destroy(pt_context *ctx)
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    free_dev(ctx->d_nodes); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
+    free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
@@ -544,12 +558,12 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     } else {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
         int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-        int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * (ctx->backend == 2 ? ctx->blocks_per_cu : ctx->sched_blocks_per_cu));
+        int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->sched_blocks_per_cu);
         if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
         a.stack_overflow = ctx->d_stack_ovf;
         a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
-        if (ctx->backend == 2) hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(path_sched_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -561,8 +575,13 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
     if (!ctx) return PT_ERR_INVALID;
     if (!name) return fail(ctx, PT_ERR_INVALID, "pt_set_option: name is NULL");
     if (std::strcmp(name, "backend") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: backend must be 0, 1 or 2");
+        if (value < 0 || value > 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: backend must be 0 or 1");
         ctx->backend = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "bvh_width") == 0) {
+        if (value != 2 && value != 4) return fail(ctx, PT_ERR_INVALID, "pt_set_option: bvh_width must be 2 or 4");
+        ctx->bvh_width = value;
         return PT_OK;
     }
     if (std::strcmp(name, "refill_threshold") == 0) {
@@ -650,8 +669,10 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     SceneDev sc = scene_dev(ctx);
     if (brute_force)
         hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
+    else if (ctx->bvh_width == 4)
+        hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     else
-        hipLaunchKernelGGL(trace_rays_bvh_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
+        hipLaunchKernelGGL(trace_rays_bvh_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(ctx->stream)) != hipSuccess ||
         (e = hipMemcpy(ids_out, d_id, (size_t)n_rays * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
         (e = hipMemcpy(t_out, d_t, (size_t)n_rays * 4, hipMemcpyDeviceToHost)) != hipSuccess) {

@@ -18,12 +18,14 @@ def sky_small():
     return pa.procedural_sky(128, 64)
 
 
-@pytest.fixture(scope="session", params=["wavefront", "sched", "mega_old"])
+@pytest.fixture(scope="session", params=["sched-bvh4", "sched-bvh2", "wavefront-bvh4"])
 def tracer(request):
-    """One libptrace context on cuda:0 per backend: the wavefront stages (default) and the
-    single persistent kernel must both match the oracle."""
+    """One libptrace context on cuda:0 per implementation variant: the scheduled persistent kernel
+    (default) over the four-wide and the binary BVH, and the wavefront stages.  All must match the oracle."""
     import pathtracing_amd as pa
     t = pa.PathTracer(0)
-    t.set_option("backend", {"sched": 0, "wavefront": 1, "mega_old": 2}[request.param])
+    backend, width = request.param.split("-bvh")
+    t.set_option("backend", {"sched": 0, "wavefront": 1}[backend])
+    t.set_option("bvh_width", int(width))
     yield t
     t.close()

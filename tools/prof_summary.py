@@ -32,7 +32,7 @@ def main(root):
             vn = "value" if "value" in cc else "counter_value"
             q = db.execute(f"select {kn}, {cn}, count(*), sum({vn}) from counters_collection group by {kn}, {cn} order by 1,2").fetchall()
             for k, c, n, v in q:
-                if "path_kernel" in k or "trace_kernel" in k or "wf_" in k:
+                if "path_" in k or "trace_" in k or "wf_" in k:
                     print(f"  {k[:40]:40s} {c:32s} dispatches={n:4d} sum={v:.6g} per_dispatch={v/n:.6g}")
         except sqlite3.OperationalError as e:
             print("  (no counters)", e)
