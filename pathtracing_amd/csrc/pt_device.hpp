@@ -228,15 +228,29 @@ __device__ __forceinline__ int32_t node_step<4>(const SceneDev &sc, int32_t node
 #define PT_CSWAP(i, j) { uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
+    // child link of a sorted key, by selects (no branches): slot = key & 3
     auto child_of = [&](uint32_t k) -> int32_t {
-        uint32_t s = k & 3u;
-        return (int32_t)(s == 0 ? q1.x : s == 1 ? q1.y : s == 2 ? q1.z : q1.w);
+        uint32_t lo = (k & 1u) ? q1.y : q1.x, hi = (k & 1u) ? q1.w : q1.z;
+        return (int32_t)((k & 2u) ? hi : lo);
     };
+    const int32_t c0 = child_of(key[0]), c1 = child_of(key[1]), c2 = child_of(key[2]), c3 = child_of(key[3]);
+    // children to stack: keys 1 .. hits-1, farthest first so that the nearest of them is popped first
+    const int np = key[3] != 0xffffffffu ? 3 : key[2] != 0xffffffffu ? 2 : key[1] != 0xffffffffu ? 1 : 0;
+    if (sp + 3 <= kStackLds) {
+        // room for three in LDS: store three unconditionally (entries past np are never read), advance by np
+        const int32_t e0 = np == 3 ? c3 : np == 2 ? c2 : c1;
+        const int32_t e1 = np == 3 ? c2 : c1;
+        st.lds[sp * kBlock] = (uint32_t)e0;
+        st.lds[(sp + 1) * kBlock] = (uint32_t)e1;
+        st.lds[(sp + 2) * kBlock] = (uint32_t)c1;
+        sp += np;
+    } else {
+        if (np == 3) stack_push(st, sp, c3);
+        if (np >= 2) stack_push(st, sp, c2);
+        if (np >= 1) stack_push(st, sp, c1);
+    }
     if (key[0] == 0xffffffffu) return sp ? stack_pop(st, sp) : kDoneNode;
-    if (key[3] != 0xffffffffu) stack_push(st, sp, child_of(key[3]));
-    if (key[2] != 0xffffffffu) stack_push(st, sp, child_of(key[2]));
-    if (key[1] != 0xffffffffu) stack_push(st, sp, child_of(key[1]));
-    return child_of(key[0]);
+    return c0;
 }
 
 // One leaf: every primitive of it against the ray, then the next stacked node (or kDoneNode).
