@@ -165,6 +165,7 @@ def main():
                          "prims_per_ray": st["prims_tested"] / max(1, r_rank),
                          "kernel_mrays_per_s": r_rank / launches / (kernel_ms * 1e-3) / 1e6},
             "image_mean_rgb": [float(x) for x in img[..., :3].reshape(-1, 3).mean(axis=0)],
+            "image_crc": int(np.bitwise_xor.reduce(np.ascontiguousarray(img).view(np.uint32).reshape(-1))),
             "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
         }
         if args.stereo and world == 1:

@@ -49,6 +49,7 @@ struct RenderArgs {
     uint32_t sample_index;
     uint32_t *work_counter;
     uint32_t *stack_overflow;     // kStackOverflow * (threads in the grid) entries
+    float4 *lane_state;           // path_sched_kernel: 4 float4 per thread of the grid
     unsigned long long *stats;    // [0] rays [1] nodes [2] prims [3] paths
     // wavefront pipeline state, one slot per work item (pt_wavefront.hpp)
     float4 *ray_o;                // (origin.xyz, _Seed)
@@ -337,53 +338,65 @@ __device__ __forceinline__ f3 sky_sample(const SceneDev &sc, f3 dir)
     return pt_scale3(c, 2.0f);
 }
 
-// Shade (SH:334-373) for the hit (t, id, rec).  Updates origin/direction/energy
-// in place and returns what SH's Shade() returns (emission or sky radiance).
-// `hit_pos` receives bestHit.position ((0,0,0) on a miss, SH:140).
-__device__ __forceinline__ f3 shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f3 &energy,
-                                    float t, int32_t id, uint32_t rec, f3 &hit_pos)
+// Shade (SH:334-373) for the hit (t, id, rec) together with the accumulation of SH:866/870:
+// result += energy_before * Shade() / spp.  Updates origin/direction/energy in place.
+// `hit_pos` receives bestHit.position ((0,0,0) on a miss, SH:140).  Values are consumed as early
+// as the arithmetic allows (emission right after the material fetch, the material folded into one
+// weight before the hemisphere sampling) to keep few registers live across the sampling code.
+__device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f3 &energy, f3 &result, float fspp,
+                                      float t, int32_t id, uint32_t rec, f3 &hit_pos)
 {
     if (!(t < PT_INF)) {
         hit_pos = pt_make3(0, 0, 0);
+        f3 sky = sky_sample(sc, d);
+        result.x += energy.x * sky.x / fspp;
+        result.y += energy.y * sky.y / fspp;
+        result.z += energy.z * sky.z / fspp;
         energy = pt_make3(0, 0, 0);
-        return sky_sample(sc, d);
+        return;
     }
-    f3 position = pt_along3(o, t, d);
+    const f3 position = pt_along3(o, t, d);
     hit_pos = position;
-    f3 normal, albedo, specular, emission;
+    f3 normal, albedo, specular;
     float smoothness;
     if (id == 0) {                                  // SH:162-166
         normal = pt_make3(0, 1, 0);
         albedo = pt_make3(0.5f, 0.5f, 0.5f);
         specular = pt_make3(0.03f, 0.03f, 0.03f);
         smoothness = 0.2f;
-        emission = pt_make3(0, 0, 0);
+        // emission 0: result += energy * 0 / spp leaves result unchanged only if energy is finite;
+        // keep the shader's arithmetic
+        result.x += energy.x * 0.0f / fspp; result.y += energy.y * 0.0f / fspp; result.z += energy.z * 0.0f / fspp;
     } else if (id <= sc.n_spheres) {                // SH:184-188
         const float4 *m = sc.sphere_mat + (size_t)(id - 1) * 4;
         float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
         normal = pt_normalize3(pt_sub3(position, xyz(m0)));
         albedo = xyz(m1); smoothness = m1.w;
         specular = xyz(m2);
-        emission = xyz(m3);
+        result.x += energy.x * m3.x / fspp; result.y += energy.y * m3.y / fspp; result.z += energy.z * m3.z / fspp;
     } else {                                        // SH:249-253
         float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
         normal = pt_normalize3(pt_cross3(xyz(b), xyz(c)));
         albedo = pt_make3(0, 0, 0);
         specular = pt_make3(0.65f, 0.65f, 0.65f);
         smoothness = 0.99f;
-        emission = pt_make3(0, 0, 0);
+        result.x += energy.x * 0.0f / fspp; result.y += energy.y * 0.0f / fspp; result.z += energy.z * 0.0f / fspp;
     }
     albedo = pt_make3(pt_min(1.0f - specular.x, albedo.x), pt_min(1.0f - specular.y, albedo.y),
                       pt_min(1.0f - specular.z, albedo.z));
     const float third = 1.0f / 3.0f;
-    float specChance = pt_dot3(specular, pt_make3(third, third, third));
-    float diffChance = pt_dot3(albedo, pt_make3(third, third, third));
-    float roulette = rng_next(rs);
+    const float specChance = pt_dot3(specular, pt_make3(third, third, third));
+    const float diffChance = pt_dot3(albedo, pt_make3(third, third, third));
+    const float roulette = rng_next(rs);
     // SH:345-365.  The specular and the diffuse branch both end in SampleHemisphere(); they are
     // merged here so that a wave runs that code once, each lane with its own axis and alpha.
     const bool spec = roulette < specChance;
     const bool diff = !spec && diffChance > 0 && roulette < specChance + diffChance;
     if (spec || diff) {
+        // (1/chance) * colour, the left factor of SH:352 / SH:359
+        const float k = 1.0f / (spec ? specChance : diffChance);
+        const f3 weight = spec ? pt_make3(k * specular.x, k * specular.y, k * specular.z)
+                               : pt_make3(k * albedo.x, k * albedo.y, k * albedo.z);
         o = pt_along3(position, 0.001f, normal);
         float alpha = 1.0f;
         f3 axis = normal;
@@ -394,21 +407,18 @@ __device__ __forceinline__ f3 shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f
         d = sample_hemisphere(rs, axis, alpha);
         if (spec) {
             float f = (alpha + 2) / (alpha + 1);
-            float k = 1.0f / specChance;
             float sd = pt_saturate(pt_dot3(normal, d) * f);
-            energy.x *= (k * specular.x) * sd;
-            energy.y *= (k * specular.y) * sd;
-            energy.z *= (k * specular.z) * sd;
+            energy.x *= weight.x * sd;
+            energy.y *= weight.y * sd;
+            energy.z *= weight.z * sd;
         } else {
-            float k = 1.0f / diffChance;
-            energy.x *= k * albedo.x;
-            energy.y *= k * albedo.y;
-            energy.z *= k * albedo.z;
+            energy.x *= weight.x;
+            energy.y *= weight.y;
+            energy.z *= weight.z;
         }
     } else {
         energy = pt_make3(0, 0, 0);
     }
-    return emission;
 }
 
 // SH:108-120 with uv = id.xy / (W,H) * 2 - 1 (SH:842)
@@ -508,36 +518,46 @@ __device__ __forceinline__ void stats_add(unsigned long long *stats, int which, 
 // A lane whose ray ends early therefore waits only until enough other lanes have ended too,
 // not until the longest ray of the wave is done, and the expensive shading code runs with
 // many lanes active.  Per-pixel arithmetic and its order are unchanged.
+// Lane states that are not a BVH node reference (all negative, none a valid leaf code: a leaf's
+// first-primitive field never reaches 2^28 - 1).
+constexpr int kIdleNode = (int)0x80000001;   // no pixel yet / pixel finished: wants a new one
+constexpr int kDeadNode = (int)0x80000002;   // no pixel and none left
+__device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && node > kDeadNode; }
+
+// Per-lane path state lives in global memory between shade phases (one slot per thread of the grid,
+// struct-of-arrays, so a wave's accesses coalesce); only what traversal needs stays in registers.
+// That keeps the register count of the traversal phases, and with it the kernel's occupancy, down.
+//   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, primary-hit distance)
+//   ls2 = (pixel x | y << 16, sample, bounce, primary id)   ls3 = (rays, nodes, prims, paths) counters
 template <int WIDE>
-__global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_kernel(const RenderArgs a)
 {
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
-    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + (blockIdx.x * kBlock + threadIdx.x), gridDim.x * kBlock};
+    __shared__ float lds_save[9 * kBlock];   // traversal-only registers parked here during a shade phase
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x, n_threads = gridDim.x * kBlock;
+    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads};
     const int lane = threadIdx.x & 63;
     const SceneDev &sc = a.sc;
+    float4 *const lsb = a.lane_state + gtid;   // slot k of this thread at lsb[k * n_threads]
+#define ls0 (lsb)
+#define ls1 (lsb + n_threads)
+#define ls2 (reinterpret_cast<int4 *>(lsb + 2 * (size_t)n_threads))
+#define ls3 (reinterpret_cast<int4 *>(lsb + 3 * (size_t)n_threads))
 
-    int32_t pix_x = -1, pix_y = 0;       // pix_x < 0: no pixel
-    bool dead = false;                    // no pixel and none left to fetch
-    int32_t sample = 0, bounce = 0;
-    float seed = 0.0f;
-    f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1), energy = pt_make3(0, 0, 0), result = pt_make3(0, 0, 0);
+    f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1);
     RaySlabs rsl = {0, 0, 0, 0, 0, 0};
-    const f3 cam_o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
-    float alpha_dist = 0.0f;
-    int32_t primary_id = -1;
     float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
-    int32_t node = kDoneNode; int sp = 0;   // node == kDoneNode with a pixel: ray finished, waits for Shade()
-    const float fspp = (float)a.spp;
-    uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_paths = 0;
+    int32_t node = kIdleNode; int sp = 0;
+    uint32_t ray_work = 0;                // nodes | prims << 16 of the current ray
+    *ls3 = make_int4(0, 0, 0, 0);
 #ifdef PT_PROFILE_PHASES
     uint32_t ph_rounds[3] = {0, 0, 0}, ph_lanes[3] = {0, 0, 0};   // wave-uniform
 #endif
 
     for (;;) {
-        const bool has_pixel = pix_x >= 0;
-        const bool inner = has_pixel && node >= 0;
-        const bool leaf = has_pixel && node < 0 && node != kDoneNode;
-        const bool waiting = (has_pixel && node == kDoneNode) || (!has_pixel && !dead);
+        const bool inner = node >= 0;
+        const bool leaf = is_leaf_ref(node);
+        const bool waiting = node == kDoneNode || node == kIdleNode;
         const int n_inner = __popcll(__ballot(inner)), n_leaf = __popcll(__ballot(leaf)), n_wait = __popcll(__ballot(waiting));
         if (n_inner + n_leaf + n_wait == 0) break;
 
@@ -546,26 +566,43 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
 #ifdef PT_PROFILE_PHASES
             ph_rounds[0]++; ph_lanes[0] += n_wait;
 #endif
-            bool new_ray = false;
-            if (has_pixel && node == kDoneNode) {
+            // Lanes that are still traversing sit this phase out; what only traversal needs is parked in
+            // LDS so that the shading code has those registers (the compiler cannot know they are idle).
+            {
+                float *sv = lds_save + threadIdx.x;
+                sv[0 * kBlock] = rsl.ix; sv[1 * kBlock] = rsl.iy; sv[2 * kBlock] = rsl.iz;
+                sv[3 * kBlock] = rsl.ox; sv[4 * kBlock] = rsl.oy; sv[5 * kBlock] = rsl.oz;
+                sv[6 * kBlock] = as_f(node); sv[7 * kBlock] = as_f(sp); sv[8 * kBlock] = as_f((int32_t)ray_work);
+            }
+            const bool was_done = node == kDoneNode, was_idle = node == kIdleNode;
+            bool new_ray = false, finished = false, no_more = false;
+            int4 cnt = make_int4(0, 0, 0, 0);
+            if (waiting) cnt = *ls3;
+            if (was_done) {
+                const int4 px = *ls2;
+                const int pix_x = px.x & 0xffff, pix_y = px.x >> 16;
+                int sample = px.y, bounce = px.z, primary_id = px.w;
+                {
+                    const uint32_t rw = (uint32_t)as_i(lds_save[threadIdx.x + 8 * kBlock]);
+                    cnt.y += (int)(rw & 0xffffu); cnt.z += (int)(rw >> 16);
+                }
                 if (a.depth == 1) {                                   // SH:799-809
                     size_t p = (size_t)pix_y * a.W + pix_x;
                     float dis = tbest / 16.0f;
                     a.result[p] = make_float4(dis, dis, dis, dis);
                     if (a.hit_ids) a.hit_ids[p] = idbest;
-                    pix_x = -1;
+                    finished = true;
                 } else {
-                    Rng rs = {seed, pixel_dot(pix_x, pix_y)};
-                    f3 e = energy, hit_pos;                           // SH:866: energy read before Shade()
-                    f3 s = shade(sc, rs, o, d, energy, tbest, idbest, recbest, hit_pos);
-                    seed = rs.seed;
-                    result.x += e.x * s.x / fspp;
-                    result.y += e.y * s.y / fspp;
-                    result.z += e.z * s.z / fspp;
+                    const float4 s0 = *ls0, s1 = *ls1;
+                    f3 energy = xyz(s0), result = xyz(s1);
+                    float alpha_dist = s1.w;
+                    Rng rs = {s0.w, pixel_dot(pix_x, pix_y)};
+                    f3 hit_pos;
+                    shade(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
                     bool path_done;
                     if (bounce == 0) {
                         primary_id = idbest;
-                        alpha_dist = pt_length3(pt_sub3(hit_pos, cam_o));
+                        alpha_dist = pt_length3(pt_sub3(hit_pos, pt_make3(a.c2w[12], a.c2w[13], a.c2w[14])));
                         path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see the note above
                     } else {
                         path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
@@ -578,21 +615,26 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
                             bounce = 0;
                             energy = pt_make3(1, 1, 1);
                             camera_ray(a, pix_x, pix_y, o, d);
-                            c_paths++;
+                            cnt.w++;
                         } else {                                       // SH:933-936
                             size_t p = (size_t)pix_y * a.W + pix_x;
                             float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
                             a.result[p] = fresh;
                             if (a.hit_ids) a.hit_ids[p] = primary_id;
                             accumulate_pixel(a, p, fresh);
-                            pix_x = -1;
+                            finished = true;
                             new_ray = false;
                         }
+                    }
+                    if (new_ray) {
+                        *ls0 = make_float4(energy.x, energy.y, energy.z, rs.seed);
+                        *ls1 = make_float4(result.x, result.y, result.z, alpha_dist);
+                        *ls2 = make_int4(px.x, sample, bounce, primary_id);
                     }
                 }
             }
             // ---- new pixels for lanes without one
-            bool need = pix_x < 0 && !dead;
+            const bool need = was_idle || finished;
             unsigned long long m = __ballot(need);
             if (m) {
                 int leader = __ffsll((long long)m) - 1;
@@ -602,31 +644,39 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
                 if (need) {
                     uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (item >= a.total_items) {
-                        dead = true;
+                        no_more = true;
                     } else {
                         int x, y;
                         if (item_pixel(a, item, x, y)) {
-                            pix_x = x; pix_y = y;
-                            sample = 0; bounce = 0;
-                            seed = a.seed;
-                            result = pt_make3(0, 0, 0);
-                            energy = pt_make3(1, 1, 1);
+                            *ls0 = make_float4(1.0f, 1.0f, 1.0f, a.seed);
+                            *ls1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            *ls2 = make_int4(x | (y << 16), 0, 0, -1);
                             camera_ray(a, x, y, o, d);
-                            c_paths++;
+                            cnt.w++;
                             new_ray = true;
                         }
                     }
                 }
             }
             // ---- set up traversal of the new rays (SH:262-269: plane first)
+            {
+                const float *sv = lds_save + threadIdx.x;
+                rsl.ix = sv[0 * kBlock]; rsl.iy = sv[1 * kBlock]; rsl.iz = sv[2 * kBlock];
+                rsl.ox = sv[3 * kBlock]; rsl.oy = sv[4 * kBlock]; rsl.oz = sv[5 * kBlock];
+                node = as_i(sv[6 * kBlock]); sp = as_i(sv[7 * kBlock]); ray_work = (uint32_t)as_i(sv[8 * kBlock]);
+            }
+            if (no_more) node = kDeadNode;
+            else if (finished && !new_ray) node = kIdleNode;   // pixel done, its replacement lay outside the tile
             if (new_ray) {
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
                 rsl = ray_slabs(o, d);
                 sp = 0;
                 node = sc.n_nodes ? 0 : kDoneNode;
-                c_rays++;
+                ray_work = 0;
+                cnt.x++;
             }
+            if (waiting) *ls3 = cnt;
             continue;
         }
 
@@ -638,9 +688,8 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
             // keep stepping while enough lanes hold an inner node; the other lanes' states cannot change
             // meanwhile, so only that one count is re-evaluated
             for (;;) {
-                const bool in = pix_x >= 0 && node >= 0;
-                if (in) { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); c_nodes++; }
-                const int still = __popcll(__ballot(pix_x >= 0 && node >= 0));
+                if (node >= 0) { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++; }
+                const int still = __popcll(__ballot(node >= 0));
 #ifdef PT_PROFILE_PHASES
                 if (still >= a.vote_node) { ph_rounds[1]++; ph_lanes[1] += still; }
 #endif
@@ -653,13 +702,18 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
 #ifdef PT_PROFILE_PHASES
         ph_rounds[2]++; ph_lanes[2] += n_leaf;
 #endif
-        if (leaf) node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, c_prims);
+        if (leaf) {
+            uint32_t np = 0;
+            node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, np);
+            ray_work += np << 16;
+        }
     }
 
-    stats_add(a.stats, 0, c_rays, lane);
-    stats_add(a.stats, 1, c_nodes, lane);
-    stats_add(a.stats, 2, c_prims, lane);
-    stats_add(a.stats, 3, c_paths, lane);
+    const int4 cnt = *ls3;
+    stats_add(a.stats, 0, (uint32_t)cnt.x, lane);
+    stats_add(a.stats, 1, (uint32_t)cnt.y, lane);
+    stats_add(a.stats, 2, (uint32_t)cnt.z, lane);
+    stats_add(a.stats, 3, (uint32_t)cnt.w, lane);
 #ifdef PT_PROFILE_PHASES
     if (lane == 0 && a.stats)
         for (int k = 0; k < 3; k++) {
@@ -669,9 +723,11 @@ __global__ __launch_bounds__(kBlock) void path_sched_kernel(const RenderArgs a)
 #endif
 }
 
-// ------------------------------------------------------- ray-query kernels
+#undef ls0
+#undef ls1
+#undef ls2
+#undef ls3
 
-// One thread per caller-supplied ray; BVH traversal.
 template <int WIDE>
 __global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uint32_t *stack_overflow, const float *od, int n,
                                                                  int32_t *ids, float *ts)

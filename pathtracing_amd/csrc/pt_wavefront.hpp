@@ -154,11 +154,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(const RenderArgs a)
             int32_t primary_id = as_i(pr.w);
             const float t = h.x; const int32_t id = as_i(h.y); const uint32_t rec = (uint32_t)as_i(h.z);
 
-            f3 e = energy, hit_pos;                               // SH:866: energy read before Shade()
-            f3 s = shade(a.sc, rs, o, d, energy, t, id, rec, hit_pos);
-            result.x += e.x * s.x / fspp;
-            result.y += e.y * s.y / fspp;
-            result.z += e.z * s.z / fspp;
+            f3 hit_pos;
+            shade(a.sc, rs, o, d, energy, result, fspp, t, id, rec, hit_pos);
             bool path_done;
             if (bounce == 0) {
                 primary_id = id;

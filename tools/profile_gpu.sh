@@ -17,6 +17,8 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
             "GRBM_GUI_ACTIVE GRBM_TA_BUSY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_LEVEL_WAVES SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL" \
             "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum" \
+            "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_IFETCH SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT" \
+            "SQ_WAVES_LT_16 SQ_WAVES_LT_32 SQ_WAVES_LT_48 SQ_WAVES_EQ_64 SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INST_LEVEL_LDS SQ_IFETCH_LEVEL" \
             "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout -s KILL 240 rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass failed: $pass"; tail -3 $OUT/pmc_$name.log; }
