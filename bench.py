@@ -24,7 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NODE_BYTES = 64      # one BVH node: both children's boxes + links (pathtracing_amd/csrc/bvh.hpp)
+NODE_BYTES = 56      # one four-wide BVH node as fetched: origin, exponents, 4 links, 4 x 6 plane bytes (csrc/bvh.hpp)
 PRIM_BYTES = 48      # one primitive record: v0, e1, e2 (+ id, kind)
 PIXEL_BYTES = 16     # RGBA32F result write per pixel
 HBM_PEAK_GBS = 8000.0
@@ -52,18 +52,18 @@ def cpu_baseline(scene, sky, args):
     import pathtracing_amd as pa
     threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
     W, H = args.width, args.height
-    tile = (W // 2 - W // 8, H // 2 - H // 8, W // 4, H // 4)
-    spp = 2
+    tile = (0, 0, W, H)
+    spp = 4
     orc = po.Oracle.from_scene(scene, sky, accel=True)
     p = pa.make_params(scene, W, H, seed=pa.frame_seed(0), spp=spp, max_bounces=args.bounces, tile=tile)
     t0 = time.perf_counter()
     _, _, st = orc.render(p, W, H, threads=threads)
     dt = time.perf_counter() - t0
     out = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-           "sample": f"central {tile[2]}x{tile[3]} tile of the {W}x{H} frame, {spp} spp, {args.bounces} bounces, "
+           "sample": f"the whole {W}x{H} frame at {spp} spp (of {args.spp}), {args.bounces} bounces, "
                      f"oracle with its own median-split BVH, {st['rays']} rays in {dt:.1f} s"}
     # the reference's own algorithm has no acceleration structure: time the exhaustive loop on a much smaller sample
-    tile2 = (W // 2 - 16, H // 2 - 9, 32, 18)
+    tile2 = (W // 2 - 96, H // 2 - 54, 192, 108)
     orc2 = po.Oracle.from_scene(scene, sky, accel=False)
     p2 = pa.make_params(scene, W, H, seed=pa.frame_seed(0), spp=1, max_bounces=args.bounces, tile=tile2)
     t0 = time.perf_counter()
@@ -73,6 +73,16 @@ def cpu_baseline(scene, sky, args):
                               "sample": f"{tile2[2]}x{tile2[3]} tile, 1 spp, every triangle tested per ray as the "
                                         f"reference does, {st2['rays']} rays in {dt2:.1f} s"}
     return out
+
+
+def measured_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes, when they were
+    taken on this workload; None otherwise (bench.py cannot run the profiler on itself)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path) or (args.scene, args.width, args.height, args.spp, args.bounces) != ("hall260k", 1920, 1080, 16, 8):
+        return None
+    t = json.load(open(path))
+    return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
 
 
 def main():
@@ -158,8 +168,9 @@ def main():
                        if world > 1 else "single GPU",
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "path_kernel", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
+                         "kernel": "path_sched_kernel<4>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_ray": (st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES) / max(1, r_rank),
                          "nodes_per_ray": st["nodes_visited"] / max(1, r_rank),
                          "prims_per_ray": st["prims_tested"] / max(1, r_rank),

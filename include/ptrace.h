@@ -115,7 +115,9 @@ void pt_destroy(pt_context *ctx);
 const char *pt_last_error(const pt_context *ctx);
 
 /* Run on an existing hipStream_t (e.g. the caller's current stream) instead of
- * the context's own; NULL restores the context's stream. */
+ * the context's own.  NULL is HIP's null stream, as everywhere in HIP;
+ * PT_STREAM_OWN goes back to the stream the context created for itself. */
+#define PT_STREAM_OWN ((void *)(intptr_t)-1)
 int pt_set_stream(pt_context *ctx, void *hip_stream);
 
 /* Implementation switches; no counterpart in the reference.

@@ -59,7 +59,7 @@ struct pt_context {
     // wavefront pipeline
     int refill_threshold = 32;
     int node_vote = 8;
-    int vote_shade = 36, vote_node = 16;
+    int vote_shade = 44, vote_node = 16;
     int sched_blocks_per_cu = 0;
     int backend = 0;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
     int trace_blocks_per_cu = 0, shade_blocks_per_cu = 0;
@@ -420,7 +420,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream)
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = hip_stream == PT_STREAM_OWN ? ctx->own_stream : (hipStream_t)hip_stream;
     return PT_OK;
 }
 

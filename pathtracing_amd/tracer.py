@@ -86,7 +86,9 @@ class PathTracer:
         self._check(self._lib.pt_bind_target(self._ctx, int(which), C.c_void_p(device_ptr)), "pt_bind_target")
 
     def set_stream(self, stream_ptr):
-        self._check(self._lib.pt_set_stream(self._ctx, C.c_void_p(stream_ptr)), "pt_set_stream")
+        """stream_ptr: a hipStream_t as an integer (0 = HIP's null stream); None = the context's own stream."""
+        ptr = C.c_void_p(-1) if stream_ptr is None else C.c_void_p(stream_ptr)
+        self._check(self._lib.pt_set_stream(self._ctx, ptr), "pt_set_stream")
 
     def render(self, params):
         self._check(self._lib.pt_render(self._ctx, C.byref(params)), "pt_render")
