@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--stereo", action="store_true", help="also time the 1080p stereo frame (2 eyes, 1 spp, 4 bounces)")
+    ap.add_argument("--no-stereo", action="store_true", help="skip the 1080p stereo frame time (2 eyes, 1 spp, 4 bounces)")
     return ap.parse_args()
 
 
@@ -69,6 +69,14 @@ def cpu_baseline(scene, sky, args):
     t0 = time.perf_counter()
     _, _, st2 = orc2.render(p2, W, H, threads=threads)
     dt2 = time.perf_counter() - t0
+    # one thread, smaller sample
+    tile1 = (W // 4, H // 4, W // 2, H // 2)
+    p1 = pa.make_params(scene, W, H, seed=pa.frame_seed(0), spp=1, max_bounces=args.bounces, tile=tile1)
+    t0 = time.perf_counter()
+    _, _, st1 = orc.render(p1, W, H, threads=1)
+    dt1 = time.perf_counter() - t0
+    out["single_thread"] = {"value": st1["rays"] / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                            "sample": f"central {tile1[2]}x{tile1[3]} tile, 1 spp, {st1['rays']} rays in {dt1:.1f} s"}
     out["exhaustive_loop"] = {"value": st2["rays"] / dt2 / 1e6, "unit": "Mrays/s",
                               "sample": f"{tile2[2]}x{tile2[3]} tile, 1 spp, every triangle tested per ray as the "
                                         f"reference does, {st2['rays']} rays in {dt2:.1f} s"}
@@ -179,7 +187,7 @@ def main():
             "image_crc": int(np.bitwise_xor.reduce(np.ascontiguousarray(img).view(np.uint32).reshape(-1))),
             "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
         }
-        if args.stereo and world == 1:
+        if not args.no_stereo and world == 1:
             out["stereo_1080p"] = stereo_frame_time(pa, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, args)

@@ -43,7 +43,9 @@ struct Builder {
     std::atomic<int32_t> next{0};
     std::atomic<int> live_threads{1};
     std::atomic<int> max_depth{0};
-    int leaf_size;
+    int leaf_size;          // largest leaf
+    int min_leaf = 1;       // ranges this small always become a leaf
+    float traversal_cost = 0.5f;   // cost of a node visit in units of one primitive test
     int max_threads;
 
     Builder(const std::vector<Aabb> &b, std::vector<uint32_t> &o, int leaf, int thr)
@@ -75,11 +77,11 @@ struct Builder {
         int d = max_depth.load();
         while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
 
-        if (n <= (uint32_t)leaf_size) { node.count = n; return me; }
+        if (n <= (uint32_t)min_leaf || n == 1) { node.count = n; return me; }
 
         // Once the remaining depth budget only just fits a balanced tree over
         // n primitives, stop using SAH and halve the range.
-        bool force_median = depth + levels_needed(n, leaf_size) + 2 >= kMaxDepth;
+        bool force_median = depth + levels_needed(n, 1) + 2 >= kMaxDepth;
         uint32_t mid = first + n / 2;
         bool split_done = false;
 
@@ -111,6 +113,14 @@ struct Builder {
                     if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
                 }
             }
+            // SAH termination: a range that may be a leaf becomes one when testing all its primitives is
+            // estimated cheaper than one more node visit plus the children's expected primitive tests
+            if (n <= (uint32_t)leaf_size) {
+                float parent_area = box_area(box);
+                float split_cost = best_axis >= 0 && parent_area > 0.0f ? traversal_cost + best_cost / parent_area
+                                                                         : std::numeric_limits<float>::infinity();
+                if ((float)n <= split_cost) { node.count = n; return me; }
+            }
             if (best_axis >= 0) {
                 float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - lo;
                 float scale = (float)kBins / ext;
@@ -123,6 +133,7 @@ struct Builder {
                 split_done = mid > first && mid < first + n;
             }
         }
+        if (!split_done && n <= (uint32_t)leaf_size) { node.count = n; return me; }   // nothing separates them
         if (!split_done) {
             // median split along the widest centroid axis (or plain halving when all centroids coincide)
             int axis = 0;
@@ -155,7 +166,7 @@ inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((
 
 }  // namespace
 
-BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads)
+BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost)
 {
     BvhResult out;
     const uint32_t n = (uint32_t)boxes.size();
@@ -166,6 +177,7 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads)
     for (uint32_t i = 0; i < n; i++) out.order[i] = i;
 
     Builder b(boxes, out.order, leaf_size, threads);
+    b.traversal_cost = traversal_cost;
     int32_t root = b.build(0, n, 0);
     out.depth = b.max_depth.load();
 

@@ -58,6 +58,8 @@ struct BvhResult {
 
 // boxes: one (already padded) box per primitive.  leaf_size <= kMaxLeafPrims.
 // threads <= 0: pick from hardware_concurrency (capped at 16).
-BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads);
+// traversal_cost: SAH cost of visiting a node, in primitive tests; ranges of <= leaf_size primitives become
+// leaves when that is estimated cheaper than splitting them.
+BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost = 0.5f);
 
 }  // namespace ptrace

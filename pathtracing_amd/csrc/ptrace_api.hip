@@ -175,7 +175,11 @@ int rebuild_scene(pt_context *ctx)
             boxes[i].lo[k] = l - pad - rel; boxes[i].hi[k] = h + pad + rel;
         }
 
-    BvhResult bvh = build_bvh(boxes, 4, 0);
+    int leaf_size = 2;   // small leaves keep the lanes of a leaf phase in step; measured best of 1..4
+    if (const char *env = std::getenv("PTRACE_LEAF")) leaf_size = std::max(1, std::min(4, std::atoi(env)));
+    float ct = 1.0f;
+    if (const char *env = std::getenv("PTRACE_SAH_CT")) ct = (float)std::atof(env);
+    BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct);
 
     std::vector<float4> recs(nP * 3);
     std::vector<uint32_t> by_id(nP);

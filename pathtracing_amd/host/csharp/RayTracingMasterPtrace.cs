@@ -1,0 +1,116 @@
+// C# host for libptrace: the parts of the reference's RayTracingMaster.cs that feed the compute
+// kernel, with every UnityEngine.ComputeShader / ComputeBuffer call replaced by the matching
+// entry point of include/ptrace.h (cited beside each call).
+//
+// UNVERIFIED SOURCE: no C# toolchain (dotnet, mono) exists where this repository is built and
+// tested.  The verified hosts are the C++ mirror (../ray_tracing_master.cpp, same method names)
+// and the ctypes harness (../../_ffi.py).  This file shows a maintainer of the reference what the
+// binding looks like; struct layouts are the reference's own (RayTracingMaster.cs:93-108).
+using System;
+using System.Collections.Generic;
+using System.Runtime.InteropServices;
+using UnityEngine;
+
+public class RayTracingMasterPtrace : MonoBehaviour
+{
+    [StructLayout(LayoutKind.Sequential)]
+    struct MeshObject { public Matrix4x4 localToWorldMatrix; public int indices_offset; public int indices_count; }   // 72 bytes
+
+    [StructLayout(LayoutKind.Sequential)]
+    struct Sphere { public Vector3 position; public float radius; public Vector3 albedo; public Vector3 specular; public float smoothness; public Vector3 emission; }   // 56 bytes
+
+    [StructLayout(LayoutKind.Sequential)]
+    unsafe struct PtFrameParams
+    {
+        public fixed float camera_to_world[16];
+        public fixed float camera_inverse_projection[16];
+        public float seed; public int samples_per_pixel; public int max_bounces; public int depth; public int render_mode;
+        public uint sample_index; public int accumulate; public int tile_x0, tile_y0, tile_w, tile_h;
+        public fixed float pixel_offset[2]; public fixed float directional_light[4];
+    }
+
+    const string Lib = "ptrace";
+    [DllImport(Lib)] static extern int pt_create(int device, out IntPtr ctx);
+    [DllImport(Lib)] static extern void pt_destroy(IntPtr ctx);
+    [DllImport(Lib)] static extern IntPtr pt_last_error(IntPtr ctx);
+    [DllImport(Lib)] static extern int pt_set_spheres(IntPtr ctx, Sphere[] spheres, int count);
+    [DllImport(Lib)] static extern int pt_set_meshes(IntPtr ctx, MeshObject[] objects, int nObjects, Vector3[] vertices, int nVertices, int[] indices, int nIndices);
+    [DllImport(Lib)] static extern int pt_update_transforms(IntPtr ctx, MeshObject[] objects, int nObjects);
+    [DllImport(Lib)] static extern int pt_set_sky(IntPtr ctx, float[] rgba, int width, int height);
+    [DllImport(Lib)] static extern int pt_resize(IntPtr ctx, int width, int height);
+    [DllImport(Lib)] static extern int pt_render(IntPtr ctx, ref PtFrameParams p);
+    [DllImport(Lib)] static extern int pt_read_converged(IntPtr ctx, float[] rgbaOut);
+
+    public int SphereSeed; public Vector2 SphereRadius = new Vector2(3.0f, 8.0f); public uint SpheresMax = 100; public float SpherePlacementRadius = 100.0f;
+    public int samplesPerPixel = 1; public uint sampleFrames = 3; public bool depth = false;
+
+    IntPtr _ctx; Camera _camera; uint _currentSample; int _width, _height; bool _geometryUploaded;
+    static readonly List<MeshObject> _meshObjects = new List<MeshObject>();
+    static readonly List<Vector3> _vertices = new List<Vector3>();
+    static readonly List<int> _indices = new List<int>();
+    static bool _meshObjectsNeedRebuilding;
+
+    void Check(int rc, string what) { if (rc != 0) throw new InvalidOperationException(what + ": " + Marshal.PtrToStringAnsi(pt_last_error(_ctx))); }
+
+    void OnEnable()
+    {
+        _camera = GetComponent<Camera>();
+        Check(pt_create(0, out _ctx), "pt_create");
+        _currentSample = 0;                                   // RayTracingMaster.cs:145
+        SetUpScene();                                         // :146
+    }
+
+    void OnDisable() { if (_ctx != IntPtr.Zero) { pt_destroy(_ctx); _ctx = IntPtr.Zero; } }   // :154-161
+
+    void SetUpScene()                                         // :315-369, unchanged up to the upload
+    {
+        UnityEngine.Random.InitState(SphereSeed);
+        var spheres = new List<Sphere>();
+        for (int i = 0; i < SpheresMax; i++)
+        {
+            var s = new Sphere();
+            s.radius = SphereRadius.x + UnityEngine.Random.value * (SphereRadius.y - SphereRadius.x);
+            Vector2 p = UnityEngine.Random.insideUnitCircle * SpherePlacementRadius;
+            s.position = new Vector3(p.x, s.radius, p.y);
+            bool skip = false;
+            foreach (var o in spheres) { float m = s.radius + o.radius; if (Vector3.SqrMagnitude(s.position - o.position) < m * m) { skip = true; break; } }
+            if (skip) continue;
+            Color c = UnityEngine.Random.ColorHSV(); float chance = UnityEngine.Random.value;
+            if (chance < 0.8f) { bool metal = chance < 0.4f; s.albedo = metal ? Vector3.zero : new Vector3(c.r, c.g, c.b); s.specular = metal ? new Vector3(c.r, c.g, c.b) : new Vector3(0.04f, 0.04f, 0.04f); s.smoothness = UnityEngine.Random.value; }
+            else { Color e = UnityEngine.Random.ColorHSV(0, 1, 0, 1, 3.0f, 8.0f); s.emission = new Vector3(e.r, e.g, e.b); }
+            spheres.Add(s);
+        }
+        Check(pt_set_spheres(_ctx, spheres.ToArray(), spheres.Count), "pt_set_spheres");   // replaces :362-368 + :536
+    }
+
+    void RebuildMeshObjectBuffers()                            // :371-413; lists are filled by RegisterObject as in the reference
+    {
+        if (!_meshObjectsNeedRebuilding) return;
+        _meshObjectsNeedRebuilding = false;
+        if (!_geometryUploaded)
+        {
+            Check(pt_set_meshes(_ctx, _meshObjects.ToArray(), _meshObjects.Count, _vertices.ToArray(), _vertices.Count, _indices.ToArray(), _indices.Count), "pt_set_meshes");   // :410-412 + :537-539
+            _geometryUploaded = true;
+        }
+        else Check(pt_update_transforms(_ctx, _meshObjects.ToArray(), _meshObjects.Count), "pt_update_transforms");
+    }
+
+    unsafe void Render()                                       // :704-747
+    {
+        RebuildMeshObjectBuffers();                            // :714
+        int w = Screen.width, h = Screen.height;
+        if (w != _width || h != _height) { Check(pt_resize(_ctx, w, h), "pt_resize"); _width = w; _height = h; }   // :542-583
+        var p = new PtFrameParams();
+        Matrix4x4 c2w = _camera.cameraToWorldMatrix, ip = _camera.projectionMatrix.inverse;                       // :489-490
+        for (int i = 0; i < 16; i++) { p.camera_to_world[i] = c2w[i]; p.camera_inverse_projection[i] = ip[i]; }  // Matrix4x4[i] is column-major
+        p.seed = UnityEngine.Random.value;                     // :530
+        p.samples_per_pixel = samplesPerPixel;                 // :531
+        p.max_bounces = 4;                                     // the shader's loop bound, RayTracingShader.compute:867
+        p.depth = depth ? 1 : 0;                               // :532
+        p.render_mode = 1;                                     // RenderMode.Default, :979
+        p.accumulate = depth ? 0 : 3;                          // AddMat.shader blend
+        p.sample_index = depth ? 0u : _currentSample;          // :805
+        Check(pt_render(_ctx, ref p), "pt_render");            // :745-747
+        if (_currentSample < sampleFrames) _currentSample++; else _currentSample = sampleFrames;   // :885-888
+    }
+}
