@@ -106,15 +106,12 @@ __device__ __forceinline__ int32_t stack_pop(const Stack &s, int &sp)
 // One primitive record against the ray; keeps the (t, id)-smallest hit, which is
 // what the reference's strict `t < bestHit.distance` loop in id order keeps
 // (SH:180, SH:245).  Sphere: SH:170-190.  Triangle: SH:192-230 + SH:243-246.
-__device__ __forceinline__ void intersect_prim(const float4 *prims, uint32_t rec, f3 o, f3 d,
-                                               float &tbest, int32_t &idbest, uint32_t &recbest)
+__device__ __forceinline__ void intersect_record(float4 a, float4 b, float4 c, uint32_t rec, f3 o, f3 d,
+                                                 float &tbest, int32_t &idbest, uint32_t &recbest)
 {
-    float4 a = prims[rec * 3 + 0];
-    float4 b = prims[rec * 3 + 1];
     int32_t id = as_i(a.w);
     float t;
     if (as_i(b.w) == 0) {
-        float4 c = prims[rec * 3 + 2];
         f3 vert0 = xyz(a), edge1 = xyz(b), edge2 = xyz(c);
         f3 pvec = pt_cross3(d, edge2);
         float det = pt_dot3(edge1, pvec);
@@ -139,6 +136,15 @@ __device__ __forceinline__ void intersect_prim(const float4 *prims, uint32_t rec
     if (t > 0 && (t < tbest || (t == tbest && id < idbest))) {
         tbest = t; idbest = id; recbest = rec;
     }
+}
+
+// All three words of a record are fetched at once (a sphere ignores the third), so that a test
+// waits for one memory round trip, not two.
+__device__ __forceinline__ void intersect_prim(const float4 *prims, uint32_t rec, f3 o, f3 d,
+                                               float &tbest, int32_t &idbest, uint32_t &recbest)
+{
+    const float4 *p = prims + (size_t)rec * 3;
+    intersect_record(p[0], p[1], p[2], rec, o, d, tbest, idbest, recbest);
 }
 
 // Reciprocal direction for the slab tests, with |d| clamped away from zero: an infinite reciprocal
@@ -260,7 +266,16 @@ __device__ __forceinline__ int32_t leaf_step(const SceneDev &sc, int32_t node, f
 {
     uint32_t enc = (uint32_t)~node;
     uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-    for (uint32_t k = 0; k < count; k++) intersect_prim(sc.prims, first + k, o, d, tbest, idbest, recbest);
+    // two records per round trip: the second one's words are fetched before the first is tested
+    // (an odd tail fetches the same record twice and tests it once)
+    for (uint32_t k = 0; k < count; k += 2) {
+        const bool two = k + 1 < count;
+        const float4 *p = sc.prims + (size_t)(first + k) * 3;
+        const float4 *q = two ? p + 3 : p;
+        const float4 a0 = p[0], b0 = p[1], c0 = p[2], a1 = q[0], b1 = q[1], c1 = q[2];
+        intersect_record(a0, b0, c0, first + k, o, d, tbest, idbest, recbest);
+        if (two) intersect_record(a1, b1, c1, first + k + 1, o, d, tbest, idbest, recbest);
+    }
     n_prims += count;
     return sp ? stack_pop(st, sp) : kDoneNode;
 }
@@ -487,7 +502,7 @@ __device__ __forceinline__ void accumulate_pixel(const RenderArgs &a, size_t p, 
 // finishing together do not queue on one address; the host adds the copies up.
 constexpr int kStatsShards = 64;
 constexpr int kStatsStride = 16;  // u64 words per shard: rays, nodes, prims, paths; with PT_PROFILE_PHASES also
-                                  // [4..9] = rounds and active lanes of the shade, node and leaf phases
+                                  // [4..9] = rounds and active lanes of the shade, node and leaf phases, [10..12] = their wave clocks
 __device__ __forceinline__ void stats_add(unsigned long long *stats, int which, uint32_t v, int lane)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -552,6 +567,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     *ls3 = make_int4(0, 0, 0, 0);
 #ifdef PT_PROFILE_PHASES
     uint32_t ph_rounds[3] = {0, 0, 0}, ph_lanes[3] = {0, 0, 0};   // wave-uniform
+    unsigned long long ph_cyc[3] = {0, 0, 0}, ph_t0 = clock64(); int ph_cur = -1;
+#define PH_SWITCH(k) { unsigned long long t_ = clock64(); if (ph_cur >= 0) ph_cyc[ph_cur] += t_ - ph_t0; ph_t0 = t_; ph_cur = (k); }
 #endif
 
     for (;;) {
@@ -564,7 +581,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         if (n_wait >= a.vote_shade || n_inner + n_leaf == 0) {
             // ================= shade phase =================
 #ifdef PT_PROFILE_PHASES
-            ph_rounds[0]++; ph_lanes[0] += n_wait;
+            ph_rounds[0]++; ph_lanes[0] += n_wait; PH_SWITCH(0)
 #endif
             // Lanes that are still traversing sit this phase out; what only traversal needs is parked in
             // LDS so that the shading code has those registers (the compiler cannot know they are idle).
@@ -683,7 +700,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         if (n_inner >= a.vote_node || n_leaf == 0) {
             // ================= node phase =================
 #ifdef PT_PROFILE_PHASES
-            ph_rounds[1]++; ph_lanes[1] += n_inner;
+            ph_rounds[1]++; ph_lanes[1] += n_inner; PH_SWITCH(1)
 #endif
             // keep stepping while enough lanes hold an inner node; the other lanes' states cannot change
             // meanwhile, so only that one count is re-evaluated
@@ -700,7 +717,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 
         // ================= leaf phase =================
 #ifdef PT_PROFILE_PHASES
-        ph_rounds[2]++; ph_lanes[2] += n_leaf;
+        ph_rounds[2]++; ph_lanes[2] += n_leaf; PH_SWITCH(2)
 #endif
         if (leaf) {
             uint32_t np = 0;
@@ -719,6 +736,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         for (int k = 0; k < 3; k++) {
             atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 4 + 2 * k], (unsigned long long)ph_rounds[k]);
             atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 5 + 2 * k], (unsigned long long)ph_lanes[k]);
+            atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 10 + k], ph_cyc[k]);
         }
 #endif
 }

@@ -335,12 +335,14 @@ int finish_epoch(pt_context *ctx)
         for (int k = 0; k < 4; k++) h[k] += part[sh * kStatsStride + k];
 #ifdef PT_PROFILE_PHASES
     {
-        unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int sh = 0; sh < kStatsShards; sh++)
-            for (int k = 0; k < 6; k++) ph[k] += part[sh * kStatsStride + 4 + k];
+            for (int k = 0; k < 9; k++) ph[k] += part[sh * kStatsStride + 4 + k];
         const char *names[3] = {"shade", "node", "leaf"};
         for (int k = 0; k < 3; k++)
-            std::fprintf(stderr, "phase %-5s rounds %12llu  lanes/round %6.2f\n", names[k], ph[2 * k], ph[2 * k] ? (double)ph[2 * k + 1] / (double)ph[2 * k] : 0.0);
+            std::fprintf(stderr, "phase %-5s rounds %12llu  lanes/round %6.2f  clocks %14llu (%5.1f%%)  clocks/round %8.1f\n", names[k], ph[2 * k],
+                         ph[2 * k] ? (double)ph[2 * k + 1] / (double)ph[2 * k] : 0.0, ph[6 + k], 100.0 * (double)ph[6 + k] / (double)(ph[6] + ph[7] + ph[8] + 1),
+                         ph[2 * k] ? (double)ph[6 + k] / (double)ph[2 * k] : 0.0);
     }
 #endif
     ctx->stats.kernel_ms = ms;
