@@ -227,7 +227,7 @@ __device__ __forceinline__ int32_t node_step<4>(const SceneDev &sc, int32_t node
         float nz = __builtin_fmaf(ubyte_f(nz4, c), sz, bz), fz = __builtin_fmaf(ubyte_f(fz4, c), sz, bz);
         float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
         float tf = fminf(fminf(fx, fy), fz);
-        bool hit = tn <= tf * 1.000002f && tn <= tbest && ((meta >> (24 + c)) & 1u);
+        bool hit = tn <= tf * 1.000002f && tn <= tbest;   // an unused slot holds an inside-out box: never entered
         // entry distance (>= 0, so its bits order like an unsigned) with the child slot in the low bits
         key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
     }
