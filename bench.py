@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-stereo", action="store_true", help="skip the 1080p stereo frame time (2 eyes, 1 spp, 4 bounces)")
+    ap.add_argument("--no-reproj", action="store_true", help="skip the renderMode-2 (temporal reprojection) frame time")
     return ap.parse_args()
 
 
@@ -189,6 +190,8 @@ def main():
         }
         if not args.no_stereo and world == 1:
             out["stereo_1080p"] = stereo_frame_time(pa, torch)
+        if not args.no_reproj and world == 1:
+            out["reproj_1080p"] = reproj_frame_time(pa, torch, scene, sky)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, args)
         print(json.dumps(out), flush=True)
@@ -229,6 +232,37 @@ def stereo_frame_time(pa, torch, frames=30):
     for t in eyes:
         t.close()
     return {"ms_per_frame": ms, "frames": frames, "config": "xr scene, 2 x 1920x1080, 1 spp, 4 bounces, mean accumulation, 1 GPU"}
+
+
+def reproj_frame_time(pa, torch, scene, sky, frames=30):
+    """ms per 1920x1080 frame in renderMode 2 (1 spp, 4 bounces, camera moving every frame, history of one
+    camera), beside the same frames in renderMode 1: the difference is the Result -> Result1 copy plus the
+    per-pixel reprojection (5 history texels)."""
+    W, H = 1920, 1080
+    t = pa.PathTracer(torch.cuda.current_device())
+    t.load_scene(scene, sky); t.resize(W, H)
+    def cam(k):
+        return (scene.eye[0] + 0.01 * k, scene.eye[1], scene.eye[2] + 0.02 * k)
+    def run(mode):
+        def frame(k):
+            if mode == 2:
+                t.set_camera_history([pa.camera_history_entry(cam(k - 1), scene.target, scene.fov, W / H)] if k else [])
+            t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k),
+                                    render_mode=mode, accumulation_frames=10))
+        for k in range(3):
+            frame(k)
+        t.sync()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            frame(3 + k)
+        t.sync()
+        return (time.perf_counter() - t0) / frames * 1e3
+    plain = run(1)
+    ms = run(2)
+    taken = float((t.read_result()[..., 3] > 0).mean())
+    t.close()
+    return {"ms_per_frame": ms, "plain_ms_per_frame": plain, "frames": frames, "nonzero_alpha_fraction": taken,
+            "config": "bench scene, 1920x1080, 1 spp, 4 bounces, renderMode 2, _AccumulationFrames 10, 1 GPU"}
 
 
 if __name__ == "__main__":

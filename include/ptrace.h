@@ -1,7 +1,8 @@
 /*
  * ptrace.h - C ABI of libptrace: the path-tracing compute kernel of
  * VirtualEngineeringLab/Pathtracing (Assets/Scripts/RayTracingShader.compute,
- * kernel CSMain, plain path-trace mode) plus progressive accumulation
+ * kernel CSMain: plain path-trace mode, renderMode 1, and depth-aware temporal
+ * reprojection, renderMode 2) plus progressive accumulation
  * (Assets/Shaders/AddMat.shader), implemented as HIP kernels for gfx950.
  *
  * Each entry point replaces one call the reference's C# host
@@ -83,14 +84,27 @@ typedef struct PtFrameParams {
     int32_t max_bounces;                 /* path segments per sample; the shader hard-codes 4
                                             (RayTracingShader.compute:866-873); must be >= 1     */
     int32_t depth;                       /* _Depth                    RayTracingMaster.cs:532     */
-    int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735); only 1 = Default */
+    int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735,977-990): 1 = Default,
+                                            2 = Reproj; the others are PT_ERR_UNSUPPORTED           */
     uint32_t sample_index;               /* _Sample of AddMat.shader:42 (RayTracingMaster.cs:805) */
     int32_t accumulate;                  /* PT_ACCUM_*                                            */
     int32_t tile_x0, tile_y0;            /* sub-rectangle of the image this dispatch renders;     */
     int32_t tile_w, tile_h;              /*   tile_w == 0 or tile_h == 0 means the whole image    */
     float pixel_offset[2];               /* _PixelOffset      uploaded, unused (RayTracingShader.compute:21,842) */
     float directional_light[4];          /* _DirectionalLight uploaded, unused (RayTracingShader.compute:19)    */
+    int32_t accumulation_frames;         /* _AccumulationFrames (RayTracingMaster.cs:738); renderMode 2 only    */
 } PtFrameParams;
+
+/* One element of each of the four history arrays _CameraToWorldOld,
+ * _CameraInverseProjectionOld, _WorldToCameraOld, _CameraProjectionOld
+ * (RayTracingShader.compute:9-16; filled from RayTracingMaster.cs:450-453,520-526). */
+typedef struct PtCameraHistory {
+    float camera_to_world[16];
+    float camera_inverse_projection[16];
+    float world_to_camera[16];
+    float camera_projection[16];
+} PtCameraHistory;
+#define PT_MAX_CAMERA_HISTORY 100        /* the arrays' declared length */
 
 /* Counters over every pt_render() issued since the previous pt_get_stats()
  * (or since pt_create); pt_get_stats() waits for those renders. */
@@ -121,10 +135,10 @@ const char *pt_last_error(const pt_context *ctx);
 int pt_set_stream(pt_context *ctx, void *hip_stream);
 
 /* Implementation switches; no counterpart in the reference.
- *   "backend"  1 (default): wavefront stages - generate / persistent trace / shade+compact+regenerate;
- *              0: one persistent kernel that does everything per lane.
- * Both produce the same image bit for bit.  The environment variable PTRACE_BACKEND=mega selects 0
- * at pt_create. */
+ *   "backend"    0 (default): one persistent kernel whose waves vote between node, leaf and shade phases;
+ *                1: wavefront stages - generate / persistent trace / shade+compact+regenerate (renderMode 1 only).
+ *   "bvh_width"  4 (default): four-child nodes with 8-bit boxes; 2: two-child nodes with float boxes.
+ * All combinations produce the same image bit for bit. */
 int pt_set_option(pt_context *ctx, const char *name, int value);
 
 /* _Spheres: new ComputeBuffer(count,56).SetData + SetBuffer (RayTracingMaster.cs:366-367,536).
@@ -148,6 +162,13 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
  * v = 0; sampled bilinearly with Repeat wrap at mip 0 (RayTracingShader.compute:331). */
 int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height);
 
+/* SetMatrixArray("_CameraInverseProjectionOld" / "_CameraToWorldOld" / "_WorldToCameraOld" /
+ * "_CameraProjectionOld") (RayTracingMaster.cs:468-471,492-495): the cameras of earlier frames,
+ * entry 0 first.  count 0..PT_MAX_CAMERA_HISTORY; entries the caller does not supply read as zero
+ * matrices, which is what the shader's uniform arrays hold before the first upload (renderMode 2
+ * then finds no valid reprojection and writes the fresh frame, as on the reference's first frame). */
+int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int count);
+
 /* InitRenderTexture (RayTracingMaster.cs:542-583): allocate Result / converged
  * / hit-id targets of width*height, zero-filled. */
 int pt_resize(pt_context *ctx, int width, int height);
@@ -158,7 +179,16 @@ int pt_resize(pt_context *ctx, int width, int height);
 int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
 
 /* SetShaderParameters + Dispatch(0, ceil(W/32), ceil(H/32), 1)
- * (RayTracingMaster.cs:716,745-747). */
+ * (RayTracingMaster.cs:716,745-747).
+ *
+ * renderMode 2 (RayTracingShader.compute:728-731,950-983): Result1 - the converged target - first
+ * receives the previous content of Result over the dispatched rectangle, as one copy that is complete
+ * before any pixel is traced; every pixel then blends its fresh radiance with the bilinear sample of
+ * Result1 at the position its primary hit had in the previous camera (history entry 0), provided that
+ * position is on screen and its stored distance agrees within 5 %.  The shader does that copy per
+ * thread inside the same dispatch, so which of its threads see old or new history is a race there;
+ * the whole-image copy is the ordering in which no thread sees another thread's new output.
+ * accumulate must be PT_ACCUM_NONE (the converged target is the history). */
 int pt_render(pt_context *ctx, const PtFrameParams *params);
 
 int pt_sync(pt_context *ctx);

@@ -330,10 +330,77 @@ static f3 shade(const PtoPrepared *p, RngState *rs, Ray *ray, RayHit hit)
 
 static int any3(f3 v) { return v.x != 0.0f || v.y != 0.0f || v.z != 0.0f; }
 
-/* CSMain for one thread id, renderMode == 1: SH:725-731 (the Result1 copy is
- * the host's business here), SH:798-809, SH:822-874, SH:933-936. */
+/* ---- renderMode 2: SH:394-411, SH:440-463, SH:950-983 ----
+ * HLSL semantics fixed here because the shader leaves them to its compiler and API:
+ * mul(float4x4, float3) uses the upper-left 3x3 block (SH:404); pwidth / pheight is an
+ * unsigned division (SH:402); a float2 texture index is truncated like a uint cast, negative
+ * and NaN to 0, and a load outside the texture gives 0 (SH:450-453, SH:968); float s =
+ * 1.0/textureSize keeps .x (SH:445); a*b+c is not fused. */
+typedef struct History {
+    const PtCameraHistory *cam;   /* entry 0 of the four *Old arrays */
+    const float *result1;         /* Result1: W*H*4, the previous frame's Result */
+} History;
+
+static void find_camera_ray(const History *hs, int W, int H, f3 direction, float *uv_out) /* SH:394-411, framesFrom 0 */
+{
+    const float *P = hs->cam->camera_projection;
+    float m11 = P[1 * 4 + 1], m22 = P[2 * 4 + 2], m23 = P[3 * 4 + 2];   /* _mRC at [C*4+R] */
+    float nearp = -m23 / m22;                                            /* SH:399 */
+    float farp = -(nearp * m22) / (1.0f - m22);                          /* SH:400 */
+    f3 pos = pt_scale3(pt_normalize3(direction), nearp + (farp - nearp)); /* SH:401 */
+    float ratio = (float)((uint32_t)W / (uint32_t)H);                    /* SH:402 */
+    f3 toCam = pt_mul_dir(hs->cam->world_to_camera, pos);                /* SH:404 */
+    float camPosZ = toCam.z;
+    float height = camPosZ / m11;                                        /* SH:406 */
+    float width = ratio * height;                                        /* SH:407 */
+    float dx = (float)W, dy = (float)H;
+    float uvx = (toCam.x - width * (dx / dy)) / width;                   /* SH:408 */
+    float uvy = (toCam.y - height) / height;                             /* SH:409 */
+    uv_out[0] = (0.5f - uvx * ((float)H * ratio / 2.0f)) - 0.00f;        /* SH:410 */
+    uv_out[1] = (0.5f - uvy * ((float)H / 2.0f)) - 0.005f;
+}
+
+static uint32_t to_uint(float v)
+{
+    if (!(v > 0.0f)) return 0u;               /* negative, zero, NaN */
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+static void load_result1(const History *hs, int W, int H, float x, float y, float *out4)
+{
+    uint32_t ix = to_uint(x), iy = to_uint(y);
+    if (ix >= (uint32_t)W || iy >= (uint32_t)H) { out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; return; }
+    const float *q = hs->result1 + 4 * ((size_t)iy * W + ix);
+    for (int k = 0; k < 4; k++) out4[k] = q[k];
+}
+
+static void bilinear_texture_sample(const History *hs, int W, int H, float Px, float Py, float *out4) /* SH:440-463 */
+{
+    float tsx = (float)W, tsy = (float)H;
+    float s = 1.0f / tsx;                                     /* SH:445 */
+    Px -= 0.5f; Py -= 0.5f;                                   /* SH:446 */
+    float pixx = Px * tsx + 0.5f, pixy = Py * tsy + 0.5f;     /* SH:447 */
+    float fx = pt_frac(Px), fy = pt_frac(Py);                 /* SH:448 */
+    pixx = pt_floor(pixx) / tsx - s / 2.0f;                   /* SH:449 */
+    pixy = pt_floor(pixy) / tsy - s / 2.0f;
+    float C11[4], C21[4], C12[4], C22[4];
+    load_result1(hs, W, H, pixx + 0.0f, pixy + 0.0f, C11);    /* SH:450-453 */
+    load_result1(hs, W, H, pixx + 1.0f, pixy + 0.0f, C21);
+    load_result1(hs, W, H, pixx + 0.0f, pixy + 1.0f, C12);
+    load_result1(hs, W, H, pixx + 1.0f, pixy + 1.0f, C22);
+    for (int k = 0; k < 4; k++) {
+        float x1 = C11[k] + fx * (C21[k] - C11[k]);           /* SH:458-461: lerp(a,b,t) = a + t*(b-a) */
+        float x2 = C12[k] + fx * (C22[k] - C12[k]);
+        out4[k] = x1 + fy * (x2 - x1);
+    }
+}
+
+/* CSMain for one thread id, renderMode 1 or 2: SH:798-809, SH:822-874, SH:933-936, SH:950-983.
+ * The prologue copy Result1 = Result (SH:728-731) is done for the whole rectangle by the caller
+ * before any pixel runs; `hs` is NULL in renderMode 1. */
 static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, int idx, int idy,
-                    float *out4, int32_t *hit_id, Counters *cn)
+                    float *out4, int32_t *hit_id, Counters *cn, const History *hs)
 {
     float fw = (float)W, fh = (float)H;
     float u = (float)idx / fw * 2.0f - 1.0f;   /* SH:802, SH:842: pixel corner, no jitter */
@@ -375,27 +442,68 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
             result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
             if (!any3(ray.energy)) break;          /* SH:871 */
         }
-        /* SH:933-936 */
-        out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
-        out4[3] = pt_length3(pt_sub3(hitPos, camo));
+        if (prm->render_mode == 2 && hs) {         /* SH:950-983 */
+            f3 origin = camo;
+            f3 originOld = pt_make3(hs->cam->camera_to_world[12], hs->cam->camera_to_world[13], hs->cam->camera_to_world[14]);
+            float reproUV[2];
+            find_camera_ray(hs, W, H, pt_sub3(hitPos, originOld), reproUV);
+            float divisor = (float)prm->accumulation_frames;
+            int take = 0;
+            float bl[4] = {0, 0, 0, 0};
+            float distOld = pt_length3(pt_sub3(hitPos, originOld));
+            if (reproUV[0] < (float)W && reproUV[0] > 0 && reproUV[1] < (float)H && reproUV[1] > 0) {
+                float direct[4];
+                bilinear_texture_sample(hs, W, H, reproUV[0], reproUV[1], bl);
+                load_result1(hs, W, H, reproUV[0], reproUV[1], direct);
+                take = (pt_abs(distOld - bl[3]) < distOld * 0.05f || direct[3] > 80.0f) && !primary_miss;
+            }
+            if (take) {                            /* SH:973 */
+                out4[0] = (bl[0] * (divisor - 1.0f)) / divisor + result.x / divisor;
+                out4[1] = (bl[1] * (divisor - 1.0f)) / divisor + result.y / divisor;
+                out4[2] = (bl[2] * (divisor - 1.0f)) / divisor + result.z / divisor;
+                out4[3] = distOld;
+            } else {                               /* SH:981 */
+                out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
+                out4[3] = pt_length3(pt_sub3(hitPos, origin));
+            }
+        } else {
+            /* SH:933-936 */
+            out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
+            out4[3] = pt_length3(pt_sub3(hitPos, camo));
+        }
     }
 }
 
 int pto_render(const PtoPrepared *p, const PtFrameParams *prm, int W, int H,
                float *result, int32_t *hit_ids, PtoStats *stats, int threads)
 {
+    if (prm && prm->render_mode != 1) return 1;
+    return pto_render_history(p, prm, NULL, 0, W, H, result, NULL, hit_ids, stats, threads);
+}
+
+int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtCameraHistory *history, int n_history,
+                       int W, int H, float *result, float *result1, int32_t *hit_ids, PtoStats *stats, int threads)
+{
     if (!p || !prm || !result || W <= 0 || H <= 0 || prm->max_bounces < 1) return 1;
+    if (prm->render_mode != 1 && prm->render_mode != 2) return 1;
+    if (prm->render_mode == 2 && !result1) return 1;
+    PtCameraHistory zero;
+    memset(&zero, 0, sizeof zero);               /* uniform arrays never uploaded hold zeros */
+    History hs = {n_history > 0 && history ? &history[0] : &zero, result1};
     int x0 = 0, y0 = 0, tw = W, th = H;
     if (prm->tile_w > 0 && prm->tile_h > 0) { x0 = prm->tile_x0; y0 = prm->tile_y0; tw = prm->tile_w; th = prm->tile_h; }
     if (x0 < 0 || y0 < 0 || x0 + tw > W || y0 + th > H) return 1;
     if (threads <= 0) threads = 1;
+    if (prm->render_mode == 2 && prm->depth != 1)    /* SH:728-731 for every dispatched thread, before any of them goes on */
+        for (int y = y0; y < y0 + th; y++)
+            memcpy(result1 + 4 * ((size_t)y * W + x0), result + 4 * ((size_t)y * W + x0), (size_t)tw * 4 * sizeof(float));
     uint64_t a = 0, b = 0, c = 0, d = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a, b, c, d)
     for (int y = y0; y < y0 + th; y++) {
         Counters cn = {0, 0, 0, 0, NULL, 0, 0};
         for (int x = x0; x < x0 + tw; x++) {
             size_t px = (size_t)y * W + x;
-            cs_main(p, prm, W, H, x, y, result + 4 * px, hit_ids ? hit_ids + px : NULL, &cn);
+            cs_main(p, prm, W, H, x, y, result + 4 * px, hit_ids ? hit_ids + px : NULL, &cn, &hs);
         }
         a += cn.trace_calls; b += cn.rays; c += cn.paths; d += cn.prims;
     }
@@ -579,8 +687,20 @@ int pto_path_dump(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, 
 {
     Counters cn = {0, 0, 0, 0, log, cap, 0};
     float out4[4]; int32_t id;
-    cs_main(p, prm, W, H, idx, idy, out4, &id, &cn);
+    cs_main(p, prm, W, H, idx, idy, out4, &id, &cn, NULL);
     return cn.log_n;
+}
+
+void pto_find_camera_ray(const PtCameraHistory *old_camera, int W, int H, const float *dir3, float *uv2)
+{
+    History hs = {old_camera, NULL};
+    find_camera_ray(&hs, W, H, pt_make3(dir3[0], dir3[1], dir3[2]), uv2);
+}
+
+void pto_bilinear_sample(const float *result1, int W, int H, float px, float py, float *out4)
+{
+    History hs = {NULL, result1};
+    bilinear_texture_sample(&hs, W, H, px, py, out4);
 }
 
 float pto_fmath(int which, float a, float b)

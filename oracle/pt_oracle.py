@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
-from pathtracing_amd._ffi import PtFrameParams  # noqa: E402  (struct layout only)
+from pathtracing_amd._ffi import PtCameraHistory, PtFrameParams  # noqa: E402  (struct layouts only)
 
 LIB_PATH = os.path.join(_HERE, "_build", "libptoracle.so")
 
@@ -44,6 +44,9 @@ def lib():
         L.pto_render.restype = C.c_int
         L.pto_render.argtypes = [C.c_void_p, C.POINTER(PtFrameParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.POINTER(PtoStats), C.c_int]
+        L.pto_render_history.restype = C.c_int
+        L.pto_render_history.argtypes = [C.c_void_p, C.POINTER(PtFrameParams), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PtoStats), C.c_int]
         L.pto_accumulate.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64]
         L.pto_rand_sequence.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pto_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -51,6 +54,8 @@ def lib():
         L.pto_sky_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_path_dump.restype = C.c_int
         L.pto_path_dump.argtypes = [C.c_void_p, C.POINTER(PtFrameParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.pto_find_camera_ray.argtypes = [C.POINTER(PtCameraHistory), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.pto_bilinear_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.pto_fmath.restype = C.c_float
         L.pto_fmath.argtypes = [C.c_int, C.c_float, C.c_float]
         _lib = L
@@ -99,6 +104,19 @@ class Oracle:
             raise ValueError("pto_render: bad arguments")
         return img, ids, {k: getattr(st, k) for k, _ in PtoStats._fields_}
 
+    def render_history(self, params, history, width, height, result, result1, threads=1):
+        """renderMode 1 or 2 with the camera history `history` (list of PtCameraHistory).  `result` (previous frame on
+        entry, new frame on return) and `result1` (the history image) are (H, W, 4) float32 arrays updated in place."""
+        assert result.dtype == np.float32 and result1.dtype == np.float32 and result.flags.c_contiguous and result1.flags.c_contiguous
+        ids = np.full((height, width), -1, np.int32)
+        st = PtoStats()
+        arr = (PtCameraHistory * max(1, len(history)))(*history)
+        rc = lib().pto_render_history(self._p, C.byref(params), C.byref(arr), len(history), width, height, result.ctypes.data,
+                                      result1.ctypes.data, ids.ctypes.data, C.byref(st), threads)
+        if rc != 0:
+            raise ValueError("pto_render_history: bad arguments")
+        return ids, {k: getattr(st, k) for k, _ in PtoStats._fields_}
+
     def trace_rays(self, origins_dirs):
         od = np.ascontiguousarray(origins_dirs, np.float32).reshape(-1, 6)
         ids = np.empty(len(od), np.int32); ts = np.empty(len(od), np.float32)
@@ -140,3 +158,15 @@ def camera_ray(c2w, ip, idx, idy, w, h):
 
 def fmath(which, a, b=0.0):
     return float(lib().pto_fmath({"sin": 0, "cos": 1, "pow": 2, "acos": 3, "atan2": 4, "log2": 5, "exp2": 6}[which], a, b))
+
+
+def find_camera_ray(old_camera, width, height, direction):
+    d = np.ascontiguousarray(direction, np.float32); out = np.zeros(2, np.float32)
+    lib().pto_find_camera_ray(C.byref(old_camera), width, height, d.ctypes.data, out.ctypes.data)
+    return out
+
+
+def bilinear_sample(result1, px, py):
+    img = np.ascontiguousarray(result1, np.float32); out = np.zeros(4, np.float32)
+    lib().pto_bilinear_sample(img.ctypes.data, img.shape[1], img.shape[0], px, py, out.ctypes.data)
+    return out

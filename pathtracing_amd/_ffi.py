@@ -26,7 +26,12 @@ class PtFrameParams(C.Structure):
                 ("depth", C.c_int32), ("render_mode", C.c_int32), ("sample_index", C.c_uint32),
                 ("accumulate", C.c_int32), ("tile_x0", C.c_int32), ("tile_y0", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("pixel_offset", C.c_float * 2),
-                ("directional_light", C.c_float * 4)]
+                ("directional_light", C.c_float * 4), ("accumulation_frames", C.c_int32)]
+
+
+class PtCameraHistory(C.Structure):
+    _fields_ = [("camera_to_world", C.c_float * 16), ("camera_inverse_projection", C.c_float * 16),
+                ("world_to_camera", C.c_float * 16), ("camera_projection", C.c_float * 16)]
 
 
 class PtStats(C.Structure):
@@ -54,6 +59,7 @@ PTRACE_SYMBOLS = {
     "pt_set_meshes": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "pt_update_transforms": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pt_set_sky": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "pt_set_camera_history": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pt_resize": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "pt_bind_target": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "pt_render": (C.c_int, [_ctx, _P(PtFrameParams)]),
@@ -72,6 +78,8 @@ PTMASTER_SYMBOLS = {
     "ptm_sky_procedural": (None, [C.c_int, C.c_int, C.c_void_p]),
     "ptm_camera_look_at": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_void_p, C.c_void_p]),
+    "ptm_camera_history_entry": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        _P(PtCameraHistory)]),
     "ptm_frame_seed": (C.c_float, [C.c_uint32]),
     "ptm_scene_create": (C.c_void_p, [C.c_char_p]),
     "ptm_scene_destroy": (None, [C.c_void_p]),
@@ -85,6 +93,7 @@ PTMASTER_SYMBOLS = {
     "ptm_master_context": (C.c_void_p, [C.c_void_p]),
     "ptm_master_load_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "ptm_master_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]),
+    "ptm_master_set_render_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "ptm_master_set_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "ptm_master_render": (C.c_int, [C.c_void_p]),
     "ptm_master_peek_params": (C.c_int, [C.c_void_p, _P(PtFrameParams)]),

@@ -65,6 +65,13 @@ struct RenderArgs {
     int32_t refill_threshold;     // wf_trace refills a wave once this many lanes are idle
     int32_t node_vote;            // wf_trace leaves the inner-node loop when fewer lanes than this hold an inner node
     int32_t vote_shade, vote_node; // path_sched_kernel phase thresholds
+    // renderMode 2 (temporal reprojection, SH:950-983)
+    int32_t render_mode;
+    float accumulation_frames;    // (float)_AccumulationFrames
+    float old_c2w[16];            // _CameraToWorldOld[0]
+    float old_w2c[16];            // _WorldToCameraOld[0]
+    float old_proj[16];           // _CameraProjectionOld[0]
+    const float4 *history;        // Result1: the previous frame's Result
 };
 
 constexpr int kBlock = 256;            // 4 waves
@@ -467,6 +474,86 @@ __device__ __forceinline__ float pixel_dot(int x, int y)
     return pt_fma((float)y * 2.0f, 78.233f, ((float)x * 2.0f) * 12.9898f);
 }
 
+// ------------------------------------------------- renderMode 2: reprojection
+//
+// HLSL semantics this code pins down (the shader leaves them to the compiler / the API):
+//   - mul(float4x4, float3) (SH:404) uses the upper-left 3x3 block;
+//   - `pwidth / pheight` (SH:402) is an unsigned integer division;
+//   - a float2 used as a texture index (SH:450-453, SH:968) is converted like HLSL's uint cast:
+//     truncation, negative values and NaN to 0; a load outside the texture returns 0;
+//   - `float s = 1.0 / textureSize` (SH:445) keeps the x component;
+//   - a * b + c is a multiplication followed by an addition.
+
+struct f2 { float x, y; };
+
+// FindCameraRay(input, 0), SH:394-411: where the direction `dir` (from the old camera's origin) lands in
+// the old camera's image, in pixels (+0.5).
+__device__ __forceinline__ f2 find_camera_ray(const RenderArgs &a, f3 dir)
+{
+    const float m11 = a.old_proj[5], m22 = a.old_proj[10], m23 = a.old_proj[14];   // _mRC = [C * 4 + R]
+    const float near = -m23 / m22;
+    const float far = -(near * m22) / (1.0f - m22);
+    const f3 pos = pt_scale3(pt_normalize3(dir), near + (far - near));
+    const float ratio = (float)((uint32_t)a.W / (uint32_t)a.H);
+    const f3 toCam = pt_mul_dir(a.old_w2c, pos);
+    const float height = toCam.z / m11;
+    const float width = ratio * height;
+    const float dimx = (float)a.W, dimy = (float)a.H;
+    const float uvx = (toCam.x - width * (dimx / dimy)) / width;
+    const float uvy = (toCam.y - height) / height;
+    f2 r;
+    r.x = 0.5f - uvx * (dimy * ratio / 2.0f);
+    r.y = (0.5f - uvy * (dimy / 2.0f)) - 0.005f;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t hlsl_ftou(float v) { return v > 0.0f ? (v >= 4294967296.0f ? 0xffffffffu : (uint32_t)v) : 0u; }
+
+__device__ __forceinline__ float4 history_load(const RenderArgs &a, float x, float y)
+{
+    const uint32_t ix = hlsl_ftou(x), iy = hlsl_ftou(y);
+    if (ix >= (uint32_t)a.W || iy >= (uint32_t)a.H) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return a.history[(size_t)iy * a.W + ix];
+}
+
+__device__ __forceinline__ float lerp1(float x, float y, float t) { return x + t * (y - x); }
+
+// BilinearTextureSample(P), SH:440-463, on Result1.
+__device__ __forceinline__ float4 bilinear_history(const RenderArgs &a, f2 P)
+{
+    const float tsx = (float)a.W, tsy = (float)a.H;
+    const float s = 1.0f / tsx;
+    P.x -= 0.5f; P.y -= 0.5f;
+    float px = P.x * tsx + 0.5f, py = P.y * tsy + 0.5f;
+    const float fx = pt_frac(P.x), fy = pt_frac(P.y);
+    px = pt_floor(px) / tsx - s / 2.0f;
+    py = pt_floor(py) / tsy - s / 2.0f;
+    const float4 C11 = history_load(a, px + 0.0f, py + 0.0f), C21 = history_load(a, px + 1.0f, py + 0.0f);
+    const float4 C12 = history_load(a, px + 0.0f, py + 1.0f), C22 = history_load(a, px + 1.0f, py + 1.0f);
+    const float4 x1 = make_float4(lerp1(C11.x, C21.x, fx), lerp1(C11.y, C21.y, fx), lerp1(C11.z, C21.z, fx), lerp1(C11.w, C21.w, fx));
+    const float4 x2 = make_float4(lerp1(C12.x, C22.x, fx), lerp1(C12.y, C22.y, fx), lerp1(C12.z, C22.z, fx), lerp1(C12.w, C22.w, fx));
+    return make_float4(lerp1(x1.x, x2.x, fy), lerp1(x1.y, x2.y, fy), lerp1(x1.z, x2.z, fy), lerp1(x1.w, x2.w, fy));
+}
+
+// SH:953-982: the value renderMode 2 writes for a finished pixel.
+__device__ __forceinline__ float4 reproject_pixel(const RenderArgs &a, f3 result, f3 hit_pos, bool sky, float alpha_dist)
+{
+    const f3 origin_old = pt_make3(a.old_c2w[12], a.old_c2w[13], a.old_c2w[14]);
+    const f3 to_hit = pt_sub3(hit_pos, origin_old);
+    const f2 uv = find_camera_ray(a, to_hit);
+    const float divisor = a.accumulation_frames;
+    if (uv.x < (float)a.W && uv.x > 0.0f && uv.y < (float)a.H && uv.y > 0.0f) {
+        const float4 bl = bilinear_history(a, uv);
+        const float dist_old = pt_length3(to_hit);
+        const float direct_w = history_load(a, uv.x, uv.y).w;
+        if ((pt_abs(dist_old - bl.w) < dist_old * 0.05f || direct_w > 80.0f) && !sky)
+            return make_float4(bl.x * (divisor - 1.0f) / divisor + result.x / divisor,
+                               bl.y * (divisor - 1.0f) / divisor + result.y / divisor,
+                               bl.z * (divisor - 1.0f) / divisor + result.z / divisor, dist_old);
+    }
+    return make_float4(result.x, result.y, result.z, alpha_dist);
+}
+
 // Converged-image update fused into the final write: AddMat.shader:44-63 with
 // its SrcAlpha/OneMinusSrcAlpha blend (:11), or a running mean, or a sum.
 __device__ __forceinline__ void accumulate_pixel(const RenderArgs &a, size_t p, float4 fresh)
@@ -542,7 +629,7 @@ __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && n
 // Per-lane path state lives in global memory between shade phases (one slot per thread of the grid,
 // struct-of-arrays, so a wave's accesses coalesce); only what traversal needs stays in registers.
 // That keeps the register count of the traversal phases, and with it the kernel's occupancy, down.
-//   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, primary-hit distance)
+//   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, t of the primary hit)
 //   ls2 = (pixel x | y << 16, sample, bounce, primary id)   ls3 = (rays, nodes, prims, paths) counters
 template <int WIDE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_kernel(const RenderArgs a)
@@ -612,14 +699,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                 } else {
                     const float4 s0 = *ls0, s1 = *ls1;
                     f3 energy = xyz(s0), result = xyz(s1);
-                    float alpha_dist = s1.w;
+                    float t_primary = s1.w;
                     Rng rs = {s0.w, pixel_dot(pix_x, pix_y)};
                     f3 hit_pos;
                     shade(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
                     bool path_done;
                     if (bounce == 0) {
                         primary_id = idbest;
-                        alpha_dist = pt_length3(pt_sub3(hit_pos, pt_make3(a.c2w[12], a.c2w[13], a.c2w[14])));
+                        t_primary = tbest;
                         path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see the note above
                     } else {
                         path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
@@ -634,8 +721,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                             camera_ray(a, pix_x, pix_y, o, d);
                             cnt.w++;
                         } else {                                       // SH:933-936
+                            // SH:860, SH:935: hitPos of the (last) sample's primary ray, (0,0,0) after a miss, and
+                            // its distance from the camera; every sample of a pixel has the same primary ray
                             size_t p = (size_t)pix_y * a.W + pix_x;
+                            f3 co, cd;
+                            camera_ray(a, pix_x, pix_y, co, cd);
+                            const bool sky = !(t_primary < PT_INF);
+                            const f3 hit_pos0 = sky ? pt_make3(0, 0, 0) : pt_along3(co, t_primary, cd);
+                            const float alpha_dist = pt_length3(pt_sub3(hit_pos0, co));
                             float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
+                            if (a.render_mode == 2) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist);
                             a.result[p] = fresh;
                             if (a.hit_ids) a.hit_ids[p] = primary_id;
                             accumulate_pixel(a, p, fresh);
@@ -645,7 +740,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                     }
                     if (new_ray) {
                         *ls0 = make_float4(energy.x, energy.y, energy.z, rs.seed);
-                        *ls1 = make_float4(result.x, result.y, result.z, alpha_dist);
+                        *ls1 = make_float4(result.x, result.y, result.z, t_primary);
                         *ls2 = make_int4(px.x, sample, bounce, primary_id);
                     }
                 }

@@ -31,6 +31,7 @@ struct pt_context {
     std::vector<float> vertices;
     std::vector<int32_t> indices;
     bool scene_dirty = true;
+    std::vector<PtCameraHistory> camera_history;   // pt_set_camera_history
 
     // device scene
     uint4 *d_nodes4 = nullptr;
@@ -528,7 +529,10 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     if (!ctx) return PT_ERR_INVALID;
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_render: params is NULL");
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_render before pt_resize");
-    if (p->render_mode != 1) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 1 (Default) is implemented");
+    if (p->render_mode != 1 && p->render_mode != 2)
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 1 (Default) and 2 (Reproj) are implemented");
+    if (p->render_mode == 2 && p->accumulate != PT_ACCUM_NONE)
+        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 2 uses the converged target as its history; accumulate must be PT_ACCUM_NONE");
     if (p->max_bounces < 1) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be >= 1");
     if (p->accumulate < PT_ACCUM_NONE || p->accumulate > PT_ACCUM_ADDMAT) return fail(ctx, PT_ERR_INVALID, "pt_render: bad accumulate mode");
     int x0 = 0, y0 = 0, tw = ctx->W, th = ctx->H;
@@ -556,13 +560,31 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     a.result = ctx->result; a.converged = ctx->conv; a.hit_ids = ctx->ids;
     a.accumulate = p->accumulate; a.sample_index = p->sample_index;
     a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
+    a.render_mode = p->render_mode;
+    a.history = ctx->conv;
+    a.accumulation_frames = (float)p->accumulation_frames;
+    {
+        // an entry that was never uploaded reads as zeros, like the shader's uniform arrays
+        PtCameraHistory h0;
+        std::memset(&h0, 0, sizeof h0);
+        if (!ctx->camera_history.empty()) h0 = ctx->camera_history[0];
+        std::memcpy(a.old_c2w, h0.camera_to_world, sizeof a.old_c2w);
+        std::memcpy(a.old_w2c, h0.world_to_camera, sizeof a.old_w2c);
+        std::memcpy(a.old_proj, h0.camera_projection, sizeof a.old_proj);
+    }
+    if (p->render_mode == 2 && p->depth != 1) {
+        // SH:728-731, Result1 = Result over the dispatched rectangle, finished before any pixel is traced
+        const size_t pitch = (size_t)ctx->W * sizeof(float4);
+        PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)y0 * ctx->W + x0, pitch, ctx->result + (size_t)y0 * ctx->W + x0, pitch,
+                                     (size_t)tw * sizeof(float4), (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
+    }
 
     if (!ctx->epoch_open) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, kStatsShards * kStatsStride * sizeof(unsigned long long), ctx->stream));
         PT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->epoch_open = true;
     }
-    if (ctx->backend == 1 && a.depth != 1) {
+    if (ctx->backend == 1 && a.depth != 1 && a.render_mode == 1) {
         if ((rc = render_wavefront(ctx, a))) return rc;
     } else {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
@@ -577,6 +599,15 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    return PT_OK;
+}
+
+int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int count)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (count < 0 || count > PT_MAX_CAMERA_HISTORY) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: count must be 0..100");
+    if (count > 0 && !entries) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: entries is NULL");
+    ctx->camera_history.assign(entries, entries + count);
     return PT_OK;
 }
 

@@ -27,7 +27,11 @@ public class RayTracingMasterPtrace : MonoBehaviour
         public float seed; public int samples_per_pixel; public int max_bounces; public int depth; public int render_mode;
         public uint sample_index; public int accumulate; public int tile_x0, tile_y0, tile_w, tile_h;
         public fixed float pixel_offset[2]; public fixed float directional_light[4];
+        public int accumulation_frames;
     }
+
+    [StructLayout(LayoutKind.Sequential)]
+    struct PtCameraHistory { public Matrix4x4 cameraToWorld, cameraInverseProjection, worldToCamera, cameraProjection; }   // 256 bytes
 
     const string Lib = "ptrace";
     [DllImport(Lib)] static extern int pt_create(int device, out IntPtr ctx);
@@ -37,12 +41,15 @@ public class RayTracingMasterPtrace : MonoBehaviour
     [DllImport(Lib)] static extern int pt_set_meshes(IntPtr ctx, MeshObject[] objects, int nObjects, Vector3[] vertices, int nVertices, int[] indices, int nIndices);
     [DllImport(Lib)] static extern int pt_update_transforms(IntPtr ctx, MeshObject[] objects, int nObjects);
     [DllImport(Lib)] static extern int pt_set_sky(IntPtr ctx, float[] rgba, int width, int height);
+    [DllImport(Lib)] static extern int pt_set_camera_history(IntPtr ctx, PtCameraHistory[] entries, int count);
     [DllImport(Lib)] static extern int pt_resize(IntPtr ctx, int width, int height);
     [DllImport(Lib)] static extern int pt_render(IntPtr ctx, ref PtFrameParams p);
     [DllImport(Lib)] static extern int pt_read_converged(IntPtr ctx, float[] rgbaOut);
 
     public int SphereSeed; public Vector2 SphereRadius = new Vector2(3.0f, 8.0f); public uint SpheresMax = 100; public float SpherePlacementRadius = 100.0f;
     public int samplesPerPixel = 1; public uint sampleFrames = 3; public bool depth = false;
+    public int renderMode = 1;                                // RenderMode.Default = 1, RenderMode.Reproj = 2 (:977-990)
+    readonly List<PtCameraHistory> _oldCameras = new List<PtCameraHistory>();   // oldIPR / oldCTW / oldWTC / oldPRJ, :450-453
 
     IntPtr _ctx; Camera _camera; uint _currentSample; int _width, _height; bool _geometryUploaded;
     static readonly List<MeshObject> _meshObjects = new List<MeshObject>();
@@ -107,8 +114,13 @@ public class RayTracingMasterPtrace : MonoBehaviour
         p.samples_per_pixel = samplesPerPixel;                 // :531
         p.max_bounces = 4;                                     // the shader's loop bound, RayTracingShader.compute:867
         p.depth = depth ? 1 : 0;                               // :532
-        p.render_mode = 1;                                     // RenderMode.Default, :979
-        p.accumulate = depth ? 0 : 3;                          // AddMat.shader blend
+        p.render_mode = renderMode;                            // :735
+        p.accumulation_frames = (int)sampleFrames;             // :738
+        p.accumulate = (depth || renderMode != 1) ? 0 : 3;     // AddMat.shader blend; in Reproj mode _converged is the history
+        Check(pt_set_camera_history(_ctx, _oldCameras.ToArray(), _oldCameras.Count), "pt_set_camera_history");   // :492-495
+        if (renderMode < 5 || renderMode > 8) _oldCameras.Clear();                                               // :513-518
+        if (renderMode < 11 && renderMode != 1)                                                                  // :520-526
+            _oldCameras.Add(new PtCameraHistory { cameraToWorld = c2w, cameraInverseProjection = ip, worldToCamera = _camera.worldToCameraMatrix, cameraProjection = _camera.projectionMatrix });
         p.sample_index = depth ? 0u : _currentSample;          // :805
         Check(pt_render(_ctx, ref p), "pt_render");            // :745-747
         if (_currentSample < sampleFrames) _currentSample++; else _currentSample = sampleFrames;   // :885-888

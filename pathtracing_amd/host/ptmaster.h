@@ -35,6 +35,11 @@ void ptm_sky_procedural(int w, int h, float *rgba);
 void ptm_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg,
                         float aspect, float z_near, float z_far, float cam_to_world[16], float cam_inv_proj[16]);
 
+/* The same camera as one element of the shader's history arrays: adds Camera.worldToCameraMatrix and
+ * Camera.projectionMatrix (RayTracingMaster.cs:522-525). */
+void ptm_camera_history_entry(const float eye[3], const float target[3], const float up[3], float fov_y_deg,
+                              float aspect, float z_near, float z_far, PtCameraHistory *out);
+
 /* Per-frame _Seed (replaces Random.value, RayTracingMaster.cs:530): frac(0.5 + k * 0.6180339). */
 float ptm_frame_seed(uint32_t k);
 
@@ -70,6 +75,8 @@ int ptm_master_load_scene(ptm_master *m, const ptm_scene *s, int sky_w, int sky_
 /* Inspector fields (RayTracingMaster.cs:73-91, 686, 991) */
 int ptm_master_configure(ptm_master *m, int width, int height, int samples_per_pixel, int max_bounces,
                          int depth, int accumulate, uint32_t sample_frames);
+/* RayTracingMaster.renderMode (RayTracingMaster.cs:977-991): 1 Default, 2 Reproj. */
+int ptm_master_set_render_mode(ptm_master *m, int render_mode);
 /* eye_offset: signed offset along the camera's right axis (stereo: -sep/2 left, +sep/2 right). */
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov_y_deg, float eye_offset);
 /* Render(): RebuildMeshObjectBuffers, SetShaderParameters, InitRenderTexture, Dispatch (RayTracingMaster.cs:704-747),

@@ -84,11 +84,9 @@ int RayTracingMaster::RebuildMeshObjectBuffers()
     return rc;
 }
 
-void RayTracingMaster::SetShaderParameters(PtFrameParams &p) const
+void RayTracingMaster::currentCamera(float e[3], float t[3]) const
 {
-    std::memset(&p, 0, sizeof p);
-    // _CameraToWorld / _CameraInverseProjection (:489-490; per-eye variants :463-467)
-    float e[3] = {eye[0], eye[1], eye[2]}, t[3] = {target[0], target[1], target[2]};
+    for (int k = 0; k < 3; k++) { e[k] = eye[k]; t[k] = target[k]; }
     if (eyeOffset != 0.0f) {
         // shift eye and target along the camera's right axis (parallel stereo axes)
         double f[3] = {t[0] - e[0], t[1] - e[1], t[2] - e[2]};
@@ -96,6 +94,14 @@ void RayTracingMaster::SetShaderParameters(PtFrameParams &p) const
         double l = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         for (int k = 0; k < 3; k++) { float d = (float)(r[k] / l) * eyeOffset; e[k] += d; t[k] += d; }
     }
+}
+
+void RayTracingMaster::FillParams(PtFrameParams &p) const
+{
+    std::memset(&p, 0, sizeof p);
+    // _CameraToWorld / _CameraInverseProjection (:489-490; per-eye variants :463-467)
+    float e[3], t[3];
+    currentCamera(e, t);
     float aspect = RenderHight > 0 ? (float)RenderWidth / (float)RenderHight : 1.0f;
     camera_look_at(e, t, up, fieldOfView, aspect, nearClip, farClip, p.camera_to_world, p.camera_inverse_projection);
     p.pixel_offset[0] = 0.0f; p.pixel_offset[1] = 0.0f;   // :529 (unused by the kernel)
@@ -105,8 +111,30 @@ void RayTracingMaster::SetShaderParameters(PtFrameParams &p) const
     p.directional_light[1] = -1.0f; p.directional_light[3] = 1.0f; // :533-534 (unused by the kernel)
     p.render_mode = renderMode;                           // :735
     p.max_bounces = maxBounces;
-    p.accumulate = depth ? PT_ACCUM_NONE : accumulate;
+    p.accumulate = (depth || renderMode != 1) ? PT_ACCUM_NONE : accumulate;
     p.sample_index = depth ? 0u : currentSample_;         // :805
+    p.accumulation_frames = (int32_t)sampleFrames;        // :738
+}
+
+int RayTracingMaster::SetShaderParameters(PtFrameParams &p)
+{
+    FillParams(p);
+    // :492-495 - the history lists as they stand, i.e. the cameras of earlier frames
+    int rc = check(pt_set_camera_history(ctx_, oldCameras_.data(), (int)oldCameras_.size()), "pt_set_camera_history");
+    if (rc) return rc;
+    // :513-518 - outside the partial-frame modes the lists restart every frame (the partial-frame
+    // modes 5-8 keep `divisions` entries; they are not implemented, so the counter test is moot)
+    if (renderMode < 5 || renderMode > 8) oldCameras_.clear();
+    // :520-526 - remember this frame's camera
+    if (renderMode < 11 && renderMode != 1) {
+        float e[3], t[3];
+        currentCamera(e, t);
+        float aspect = RenderHight > 0 ? (float)RenderWidth / (float)RenderHight : 1.0f;
+        PtCameraHistory h;
+        camera_history_entry(e, t, up, fieldOfView, aspect, nearClip, farClip, &h);
+        oldCameras_.push_back(h);
+    }
+    return PT_OK;
 }
 
 int RayTracingMaster::InitRenderTexture()
@@ -124,7 +152,7 @@ int RayTracingMaster::Render()
     int rc;
     if ((rc = RebuildMeshObjectBuffers())) return rc;     // :714
     PtFrameParams p;
-    SetShaderParameters(p);                               // :716
+    if ((rc = SetShaderParameters(p))) return rc;         // :716
     if ((rc = InitRenderTexture())) return rc;            // :718
     if (targetW_ == 0 || targetH_ == 0) return PT_OK;     // :721
     if ((rc = check(pt_render(ctx_, &p), "pt_render"))) return rc;   // :735-747
@@ -160,6 +188,12 @@ void ptm_camera_look_at(const float eye[3], const float target[3], const float u
                         float z_near, float z_far, float c2w[16], float ip[16])
 {
     camera_look_at(eye, target, up, fov, aspect, z_near, z_far, c2w, ip);
+}
+
+void ptm_camera_history_entry(const float eye[3], const float target[3], const float up[3], float fov, float aspect,
+                              float z_near, float z_far, PtCameraHistory *out)
+{
+    camera_history_entry(eye, target, up, fov, aspect, z_near, z_far, out);
 }
 
 float ptm_frame_seed(uint32_t k) { return frame_seed(k); }
@@ -213,6 +247,7 @@ int ptm_master_configure(ptm_master *m, int width, int height, int spp, int max_
     r.depth = depth != 0; r.accumulate = accumulate; r.sampleFrames = sample_frames;
     return PT_OK;
 }
+int ptm_master_set_render_mode(ptm_master *m, int render_mode) { m->m->renderMode = render_mode; return PT_OK; }
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov, float eye_offset)
 {
     std::memcpy(m->m->eye, eye, 12); std::memcpy(m->m->target, target, 12);
@@ -220,7 +255,7 @@ int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[
     return PT_OK;
 }
 int ptm_master_render(ptm_master *m) { return m->m->Render(); }
-int ptm_master_peek_params(ptm_master *m, PtFrameParams *out) { m->m->SetShaderParameters(*out); return PT_OK; }
+int ptm_master_peek_params(ptm_master *m, PtFrameParams *out) { m->m->FillParams(*out); return PT_OK; }
 void ptm_master_reset_accumulation(ptm_master *m) { m->m->ResetAccumulation(); }
 uint32_t ptm_master_current_sample(const ptm_master *m) { return m->m->currentSample(); }
 uint32_t ptm_master_frame_index(const ptm_master *m) { return m->m->frameIndex(); }

@@ -43,7 +43,8 @@ public:
     int UpdateObject(int object, const float local_to_world[16]);
 
     int Render();                                       // :704-747 (+ :885-888)
-    void SetShaderParameters(PtFrameParams &p) const;   // :455-540, :735-738
+    int SetShaderParameters(PtFrameParams &p);          // :455-540, :735-738 (uploads and then updates the camera history)
+    void FillParams(PtFrameParams &p) const;            // the per-frame uniforms alone, no side effects
     void ResetAccumulation() { currentSample_ = 0; }    // :145, :753
     uint32_t currentSample() const { return currentSample_; }
     uint32_t frameIndex() const { return frame_; }
@@ -64,6 +65,8 @@ private:
     int targetW_ = 0, targetH_ = 0;                     // size of _target
     uint32_t currentSample_ = 0;                        // _currentSample :45
     uint32_t frame_ = 0;                                // frames dispatched; drives the per-frame _Seed
+    std::vector<PtCameraHistory> oldCameras_;           // oldIPR / oldCTW / oldWTC / oldPRJ :450-453, one struct per entry
+    void currentCamera(float e[3], float t[3]) const;   // eye and target with the stereo offset applied
 };
 
 }  // namespace ptm

@@ -27,6 +27,10 @@ int sphere_field(int sphere_seed, uint32_t spheres_max, float rmin, float rmax, 
 void sky_procedural(int w, int h, float *rgba);
 void camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
                     float z_near, float z_far, float c2w[16], float ip[16]);
+// The same camera as one element of the shader's four history arrays (cameraToWorld, inverse projection,
+// worldToCamera, projection - RayTracingMaster.cs:522-525).
+void camera_history_entry(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                          float z_near, float z_far, PtCameraHistory *out);
 float frame_seed(uint32_t k);
 
 // What the reference keeps in its static lists (RayTracingMaster.cs:47-52) plus the sphere list.

@@ -301,6 +301,30 @@ void camera_look_at(const float eye[3], const float target[3], const float up[3]
     std::memcpy(ip, p, sizeof p);
 }
 
+void camera_history_entry(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                          float z_near, float z_far, PtCameraHistory *out)
+{
+    camera_look_at(eye, target, up, fov_y_deg, aspect, z_near, z_far, out->camera_to_world, out->camera_inverse_projection);
+    // worldToCamera: inverse of the rigid cameraToWorld (rotation transposed, translation -R^T * eye)
+    const float *m = out->camera_to_world;
+    float *w = out->world_to_camera;
+    std::memset(w, 0, sizeof(float) * 16);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) w[c * 4 + r] = m[r * 4 + c];
+    for (int r = 0; r < 3; r++)
+        w[12 + r] = (float)-((double)m[r * 4 + 0] * eye[0] + (double)m[r * 4 + 1] * eye[1] + (double)m[r * 4 + 2] * eye[2]);
+    w[15] = 1.0f;
+    // OpenGL perspective matrix (what Camera.projectionMatrix holds)
+    double tf = std::tan(fov_y_deg * M_PI / 360.0);
+    float *q = out->camera_projection;
+    std::memset(q, 0, sizeof(float) * 16);
+    q[0] = (float)(1.0 / (aspect * tf));                               // (0,0)
+    q[5] = (float)(1.0 / tf);                                          // (1,1)
+    q[10] = (float)(-(z_far + z_near) / (double)(z_far - z_near));     // (2,2)
+    q[11] = -1.0f;                                                     // (3,2)
+    q[14] = (float)(-2.0 * z_far * z_near / (double)(z_far - z_near)); // (2,3)
+}
+
 float frame_seed(uint32_t k)
 {
     double v = 0.5 + (double)k * 0.6180339;

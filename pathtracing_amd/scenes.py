@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import PtFrameParams, PtMeshObject, PtSphere
+from ._ffi import PtCameraHistory, PtFrameParams, PtMeshObject, PtSphere
 
 SCENE_NAMES = ("spheres", "xr", "fixture", "blob70k", "hall260k", "city10m")
 
@@ -80,8 +80,17 @@ def camera_matrices(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1, z_fa
     return c2w, ip
 
 
+def camera_history_entry(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1, z_far=100.0):
+    """One PtCameraHistory (cameraToWorld, inverse projection, worldToCamera, projection) for a look-at camera."""
+    e = np.asarray(eye, np.float32); t = np.asarray(target, np.float32); u = np.asarray(up, np.float32)
+    h = PtCameraHistory()
+    _ffi.ptmaster().ptm_camera_history_entry(e.ctypes.data, t.ctypes.data, u.ctypes.data, fov_deg, aspect, z_near, z_far,
+                                             C.byref(h))
+    return h
+
+
 def make_params(scene, width, height, *, seed=0.5, spp=1, max_bounces=8, depth=0, accumulate=0, sample_index=0,
-                tile=None, eye=None, target=None, fov=None):
+                tile=None, eye=None, target=None, fov=None, render_mode=1, accumulation_frames=0):
     """PtFrameParams for `scene`'s default (or the given) camera."""
     c2w, ip = camera_matrices(scene.eye if eye is None else eye, scene.target if target is None else target,
                               scene.fov if fov is None else fov, width / height)
@@ -89,7 +98,8 @@ def make_params(scene, width, height, *, seed=0.5, spp=1, max_bounces=8, depth=0
     p.camera_to_world[:] = c2w.tolist()
     p.camera_inverse_projection[:] = ip.tolist()
     p.seed = seed; p.samples_per_pixel = spp; p.max_bounces = max_bounces; p.depth = depth
-    p.render_mode = 1; p.sample_index = sample_index; p.accumulate = accumulate
+    p.render_mode = render_mode; p.sample_index = sample_index; p.accumulate = accumulate
+    p.accumulation_frames = accumulation_frames
     if tile is not None:
         p.tile_x0, p.tile_y0, p.tile_w, p.tile_h = tile
     p.directional_light[1] = -1.0; p.directional_light[3] = 1.0

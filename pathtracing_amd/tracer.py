@@ -77,6 +77,12 @@ class PathTracer:
         self.set_meshes(scene.objects, scene.vertices, scene.indices)
         self.set_sky(sky)
 
+    def set_camera_history(self, entries):
+        """entries: sequence of PtCameraHistory, the cameras of earlier frames, most recent upload order as the host keeps it."""
+        from ._ffi import PtCameraHistory
+        arr = (PtCameraHistory * max(1, len(entries)))(*entries)
+        self._check(self._lib.pt_set_camera_history(self._ctx, C.byref(arr), len(entries)), "pt_set_camera_history")
+
     # ---- targets / render ---------------------------------------------------
     def resize(self, width, height):
         self._check(self._lib.pt_resize(self._ctx, int(width), int(height)), "pt_resize")

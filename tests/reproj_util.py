@@ -1,0 +1,45 @@
+"""Shared driver for the renderMode-2 (temporal reprojection) tests: the same frame sequence through the
+oracle or through libptrace.  The camera moves a little every frame, as a host following
+RayTracingMaster.cs:492-526 would present it: the history holds the previous frame's camera."""
+import numpy as np
+
+import pathtracing_amd as pa
+
+
+def camera_at(scene, k, step=(0.12, 0.05, 0.2)):
+    eye = tuple(float(scene.eye[i]) + k * step[i] for i in range(3))
+    return eye, tuple(float(v) for v in scene.target)
+
+
+def frame_params(scene, W, H, k, spp, max_bounces, frames_n, step=(0.12, 0.05, 0.2), tile=None, depth=0):
+    eye, target = camera_at(scene, k, step)
+    p = pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=spp, max_bounces=max_bounces, eye=eye, target=target,
+                       render_mode=2, accumulation_frames=frames_n, tile=tile, depth=depth)
+    h = pa.camera_history_entry(eye, target, scene.fov, W / H)
+    return p, h
+
+
+def oracle_sequence(oracle, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5, threads=4, **kw):
+    result = np.zeros((H, W, 4), np.float32); result1 = np.zeros((H, W, 4), np.float32)
+    hist = []
+    out = []
+    for k in range(n_frames):
+        p, h = frame_params(scene, W, H, k, spp, max_bounces, frames_n, **kw)
+        ids, st = oracle.render_history(p, hist, W, H, result, result1, threads=threads)
+        hist = [h]
+        out.append((result.copy(), result1.copy(), ids, st))
+    return out
+
+
+def gpu_sequence(tracer, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5, **kw):
+    tracer.write_converged(np.zeros((H, W, 4), np.float32))
+    hist = []
+    out = []
+    for k in range(n_frames):
+        p, h = frame_params(scene, W, H, k, spp, max_bounces, frames_n, **kw)
+        tracer.set_camera_history(hist)
+        tracer.stats()
+        tracer.render(p)
+        hist = [h]
+        out.append((tracer.read_result(), tracer.read_converged(), tracer.read_hit_ids(), tracer.stats()))
+    return out

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
 same inputs.  fp32 images are compared BIT-EXACT (tolerance 0): both sides are
 written on the intrinsics of include/ptrace_fmath.h with contraction off."""
+import os
+
 import numpy as np
 import pytest
 
@@ -323,3 +325,112 @@ def test_ten_million_triangles(tracer):
     dep = tracer.read_result()
     hit = ids >= 0
     assert np.isfinite(img).all() and np.allclose(dep[hit][:, 0] * 16.0, img[hit][:, 3], rtol=2e-6) and np.isinf(dep[~hit]).all()
+
+
+# ---------------------------------------------------- renderMode 2 (reprojection)
+
+def test_reprojection_sequence_matches_oracle_bit_exact(tracer):
+    """Three frames with a moving camera: Result and Result1 of every frame equal the oracle's, bit for bit."""
+    from reproj_util import gpu_sequence, oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    W, H = 64, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_sequence(o, s, W, H, 3, spp=2, max_bounces=4, frames_n=5)
+    got = gpu_sequence(tracer, s, W, H, 3, spp=2, max_bounces=4, frames_n=5)
+    for k in range(3):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"Result1, frame {k}"
+        assert (got[k][2] == want[k][2]).all()
+        assert got[k][3]["rays"] == want[k][3]["rays"]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reproj_64x36.npz"))
+    assert (got[2][0].view(np.uint32) == g["result2"].view(np.uint32)).all()
+    taken = (np.abs(got[2][0][..., 3] - g["plain_alpha2"]) > 0).sum()
+    assert taken == int(g["taken2"]) and taken > 1000       # the history really is used
+
+
+def test_reprojection_mesh_scene_odd_size_and_tile(tracer):
+    from reproj_util import frame_params, gpu_sequence, oracle_sequence
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(256, 128)
+    W, H = 131, 77
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_sequence(o, s, W, H, 2, spp=1, max_bounces=8, frames_n=10, threads=8)
+    got = gpu_sequence(tracer, s, W, H, 2, spp=1, max_bounces=8, frames_n=10)
+    for k in range(2):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"frame {k}"
+    # a third frame over a sub-rectangle only: Result1 and Result change inside it and nowhere else
+    tile = (16, 8, 70, 40)
+    p, h = frame_params(s, W, H, 2, 1, 8, 10, tile=tile)
+    hist = [frame_params(s, W, H, 1, 1, 8, 10)[1]]
+    res, res1 = want[1][0].copy(), want[1][1].copy()
+    o.render_history(p, hist, W, H, res, res1, threads=8)
+    tracer.set_camera_history(hist); tracer.render(p)
+    assert (tracer.read_result().view(np.uint32) == res.view(np.uint32)).all()
+    assert (tracer.read_converged().view(np.uint32) == res1.view(np.uint32)).all()
+    x0, y0, tw, th = tile
+    outside = np.ones((H, W), bool); outside[y0:y0 + th, x0:x0 + tw] = False
+    assert (res[outside] == want[1][0][outside]).all() and (res1[outside] == want[1][1][outside]).all()
+
+
+def test_reprojection_without_history_and_errors(tracer):
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    W, H = 40, 24
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    tracer.set_camera_history([])
+    plain = pa.make_params(s, W, H, seed=0.25, spp=1, max_bounces=4)
+    tracer.render(plain); a = tracer.read_result()
+    p2 = pa.make_params(s, W, H, seed=0.25, spp=1, max_bounces=4, render_mode=2, accumulation_frames=8)
+    tracer.render(p2)
+    assert (tracer.read_result().view(np.uint32) == a.view(np.uint32)).all()     # zero matrices: fresh frame (SH:981)
+    assert (tracer.read_converged().view(np.uint32) == a.view(np.uint32)).all()  # Result1 = previous Result (SH:730)
+    bad = pa.make_params(s, W, H, render_mode=2, accumulate=pa.PT_ACCUM_MEAN)
+    with pytest.raises(pa.PtraceError, match="accumulate"):
+        tracer.render(bad)
+    with pytest.raises(pa.PtraceError, match="renderMode"):
+        tracer.render(pa.make_params(s, W, H, render_mode=0))
+    # depth dispatch in renderMode 2: SH:799-809 returns before any reprojection
+    d2 = pa.make_params(s, W, H, depth=1, render_mode=2)
+    d1 = pa.make_params(s, W, H, depth=1)
+    tracer.render(d1); want = tracer.read_result()
+    tracer.render(d2)
+    assert (tracer.read_result().view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_master_mirror_reproj_mode_keeps_the_camera_history():
+    """The C++ RayTracingMaster mirror in renderMode 2 (RayTracingMaster.cs:492-526): frame k reprojects from
+    the camera of frame k-1.  The oracle renders the same frames from the parameters the mirror uploads and a
+    history list kept the way the C# keeps it."""
+    import ctypes as C
+    from pathtracing_amd import _ffi
+    lib = _ffi.ptmaster()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        W, H = 64, 36
+        assert lib.ptm_master_load_scene(h, s.handle, 128, 64) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, W, H, 1, 4, 0, pa.PT_ACCUM_NONE, 6)
+        lib.ptm_master_set_render_mode(h, 2)
+        orc = po.Oracle.from_scene(s, pa.procedural_sky(128, 64), accel=False)
+        ctx = lib.ptm_master_context(h)
+        res = np.zeros((H, W, 4), np.float32); res1 = np.zeros((H, W, 4), np.float32)
+        hist = []
+        taken = 0
+        for k in range(3):
+            eye = (s.eye[0] + 0.1 * k, s.eye[1], s.eye[2] + 0.15 * k)
+            lib.ptm_master_set_camera(h, (C.c_float * 3)(*eye), (C.c_float * 3)(*s.target), C.c_float(s.fov), C.c_float(0.0))
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            assert p.render_mode == 2 and p.accumulation_frames == 6 and p.accumulate == pa.PT_ACCUM_NONE
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            orc.render_history(p, hist, W, H, res, res1, threads=4)
+            hist = [pa.camera_history_entry(eye, s.target, s.fov, W / H)]
+            got = np.empty((H, W, 4), np.float32)
+            assert _ffi.ptrace().pt_read_result(ctx, got.ctypes.data) == 0
+            _assert_same_image(got, res, f"master reproj frame {k}")
+            plain = pa.PtFrameParams.from_buffer_copy(p); plain.render_mode = 1
+            taken += int((orc.render(plain, W, H, threads=4)[0][..., 3] != res[..., 3]).sum())
+        assert taken > 500
+    finally:
+        lib.ptm_master_destroy(h)

@@ -329,3 +329,86 @@ def test_bunny_obj_from_reference_checkout():
     ia, ida, _ = a.render(p, 48, 27, threads=4); ib, idb, _ = b.render(p, 48, 27, threads=4)
     assert (ida == idb).all() and (ia.view(np.uint32) == ib.view(np.uint32)).all()
     assert (ida > len(s.spheres) + 320).any()                     # the bunny is hit
+
+
+# ---------------------------------------------------- renderMode 2 (reprojection)
+
+def test_find_camera_ray_is_the_old_cameras_projection():
+    """FindCameraRay (SH:394-411) returns the pixel position (+0.5, and 0.005 less in y) at which the old
+    camera saw a world point; checked against projection * worldToCamera done in float64."""
+    W, H = 1920, 1080
+    eye, target = (1.0, 4.0, -9.0), (0.5, 1.0, 0.0)
+    h = pa.camera_history_entry(eye, target, 60.0, W / H)
+    w2c = np.array(h.world_to_camera, np.float64).reshape(4, 4).T      # column-major storage
+    prj = np.array(h.camera_projection, np.float64).reshape(4, 4).T
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        x = np.array([rng.uniform(-6, 6), rng.uniform(0, 5), rng.uniform(-2, 8), 1.0])
+        clip = prj @ (w2c @ x)
+        ndc = clip[:2] / clip[3]
+        want = (ndc + 1.0) * np.array([W, H]) / 2.0 + np.array([0.5, 0.5 - 0.005])
+        got = po.find_camera_ray(h, W, H, x[:3] - np.array(eye))
+        assert np.allclose(got, want, atol=2e-2), (got, want)
+
+
+def test_find_camera_ray_without_history_is_nan():
+    """Before the first upload the shader's history arrays hold zeros: near = -0/0, so no comparison of
+    SH:965-968 can hold and the pixel takes the fresh value."""
+    z = pa.PtCameraHistory()
+    assert np.isnan(po.find_camera_ray(z, 64, 36, (0.0, -1.0, 2.0))).all()
+
+
+def test_bilinear_texture_sample_kat():
+    """BilinearTextureSample (SH:440-463) on a ramp image: away from integer positions it is the usual
+    bilinear filter with texel centres at integers + 0.5; at an exactly integer P - 0.5 its index
+    arithmetic (floor(...)/size - s/2, truncated) lands one texel low in both axes; loads outside
+    the texture read as zero."""
+    W, H = 64, 36
+    img = np.zeros((H, W, 4), np.float32)
+    img[..., 0] = np.arange(W, dtype=np.float32)[None, :]
+    img[..., 1] = np.arange(H, dtype=np.float32)[:, None]
+    img[..., 3] = 1.0
+    got = po.bilinear_sample(img, 10.75 + 0.5, 20.25 + 0.5)
+    assert np.allclose(got, [10.75, 20.25, 0.0, 1.0], atol=1e-5)
+    got = po.bilinear_sample(img, 10.0 + 0.5, 20.0 + 0.5)              # f = 0: C11 alone, and C11 is texel (9, 19)
+    assert (got == np.array([9.0, 19.0, 0.0, 1.0], np.float32)).all()
+    got = po.bilinear_sample(img, 63.75 + 0.5, 5.5 + 0.5)              # right neighbours are outside: weight .75 of zero
+    assert np.allclose(got, [63.0 * 0.25, 5.5 * 0.25, 0.0, 0.25], atol=1e-5)
+
+
+def test_reprojection_static_camera_properties():
+    from reproj_util import oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    W, H, N = 48, 27, 4
+    seq = oracle_sequence(o, s, W, H, 3, spp=1, max_bounces=4, frames_n=N, step=(0, 0, 0))
+    plain = []
+    for k in range(3):
+        p = pa.make_params(s, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4)
+        plain.append(o.render(p, W, H)[0])
+    r0, h0, ids, _ = seq[0]
+    assert (r0 == plain[0]).all()                      # no history yet: the fresh frame (SH:981)
+    assert (h0 == 0).all()                             # Result1 = the (empty) previous Result
+    r1, h1, _, _ = seq[1]
+    assert (h1 == r0).all()                            # SH:730
+    sky_px = ids < 0
+    assert (r1[sky_px] == plain[1][sky_px]).all()      # !skyboxS fails: fresh value
+    hit = ~sky_px
+    # same camera: the reprojected distance is the pixel's own distance, so the alpha channel is unchanged ...
+    assert np.allclose(r1[hit][:, 3], plain[1][hit][:, 3], rtol=1e-6)
+    # ... and wherever the history was taken, colour = (history * (N-1) + fresh) / N with history from frame 0
+    taken = hit & (np.abs(r1[..., :3] - plain[1][..., :3]).max(-1) > 0)
+    assert taken.sum() > 0.5 * hit.sum()
+    lo = np.minimum(plain[1][..., :3] / N, plain[1][..., :3] / N + r0[..., :3].max() * (N - 1) / N)
+    assert (r1[..., :3][taken] >= lo[taken] - 1e-6).all()
+
+
+def test_reprojection_golden_sequence():
+    from reproj_util import oracle_sequence
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "reproj_64x36.npz"))
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    o = po.Oracle.from_scene(s, sky)
+    seq = oracle_sequence(o, s, 64, 36, 3, spp=2, max_bounces=4, frames_n=5)
+    for k, (res, hist, ids, st) in enumerate(seq):
+        assert (res.view(np.uint32) == g[f"result{k}"].view(np.uint32)).all(), k
+    assert int(g["taken2"]) == int((np.abs(seq[2][0][..., 3] - g["plain_alpha2"]) > 0).sum())

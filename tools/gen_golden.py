@@ -42,3 +42,17 @@ for name, kw in {"spp1_b4": dict(spp=1, max_bounces=4), "spp1_b8": dict(spp=1, m
 np.savez_compressed(os.path.join(out, "fixture_64x36.npz"), rand_pixels=np.array(pix), rand=rand, cam_c2w=c2w, cam_ip=ip,
                     cam_pixels=np.array(cam_px), cam_rays=cam, **res)
 print("wrote", os.path.join(out, "fixture_64x36.npz"), {k: v.shape for k, v in res.items()})
+
+# (viii) renderMode 2: three frames of the fixture scene with a moving camera, 2 spp, 4 bounces, _AccumulationFrames 5
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from reproj_util import frame_params, oracle_sequence  # noqa: E402
+
+seq = oracle_sequence(o, s, W, H, 3, spp=2, max_bounces=4, frames_n=5)
+p2, _ = frame_params(s, W, H, 2, 2, 4, 5)
+p2.render_mode = 1
+plain2 = o.render(p2, W, H, threads=4)[0]
+rp = {f"result{k}": r for k, (r, h, ids, st) in enumerate(seq)}
+rp["plain_alpha2"] = plain2[..., 3]
+rp["taken2"] = np.int64((np.abs(seq[2][0][..., 3] - plain2[..., 3]) > 0).sum())
+np.savez_compressed(os.path.join(out, "reproj_64x36.npz"), **rp)
+print("wrote reproj_64x36.npz; pixels that took the history in frame 2:", int(rp["taken2"]), "of", W * H)
