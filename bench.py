@@ -235,9 +235,10 @@ def stereo_frame_time(pa, torch, frames=30):
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):
-    """ms per 1920x1080 frame in renderMode 2 (1 spp, 4 bounces, camera moving every frame, history of one
-    camera), beside the same frames in renderMode 1: the difference is the Result -> Result1 copy plus the
-    per-pixel reprojection (5 history texels)."""
+    """ms per 1920x1080 frame (1 spp, 4 bounces, camera moving every frame, history of one camera) in renderMode 1
+    (plain), 2 (temporal reprojection: Result -> Result1 copy + 5 history texels per pixel, fused into the path
+    kernel) and 0 (the reference's start-up mode: reprojection into Result2, then the a-trous filter and the TAA
+    resolve as two streaming kernels)."""
     W, H = 1920, 1080
     t = pa.PathTracer(torch.cuda.current_device())
     t.load_scene(scene, sky); t.resize(W, H)
@@ -245,7 +246,7 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
         return (scene.eye[0] + 0.01 * k, scene.eye[1], scene.eye[2] + 0.02 * k)
     def run(mode):
         def frame(k):
-            if mode == 2:
+            if mode != 1:
                 t.set_camera_history([pa.camera_history_entry(cam(k - 1), scene.target, scene.fov, W / H)] if k else [])
             t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k),
                                     render_mode=mode, accumulation_frames=10))
@@ -258,11 +259,13 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
         t.sync()
         return (time.perf_counter() - t0) / frames * 1e3
     plain = run(1)
-    ms = run(2)
-    taken = float((t.read_result()[..., 3] > 0).mean())
+    ms2 = run(2)
+    ms0 = run(0)
+    shown = t.read_result()
     t.close()
-    return {"ms_per_frame": ms, "plain_ms_per_frame": plain, "frames": frames, "nonzero_alpha_fraction": taken,
-            "config": "bench scene, 1920x1080, 1 spp, 4 bounces, renderMode 2, _AccumulationFrames 10, 1 GPU"}
+    return {"ms_per_frame": ms2, "plain_ms_per_frame": plain, "denoise_mode_ms_per_frame": ms0, "frames": frames,
+            "denoise_mode_image_mean": float(shown[..., :3].mean()),
+            "config": "bench scene, 1920x1080, 1 spp, 4 bounces, _AccumulationFrames 10, 1 GPU; renderMode 2 / 1 / 0"}
 
 
 if __name__ == "__main__":

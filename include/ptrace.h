@@ -1,8 +1,9 @@
 /*
  * ptrace.h - C ABI of libptrace: the path-tracing compute kernel of
  * VirtualEngineeringLab/Pathtracing (Assets/Scripts/RayTracingShader.compute,
- * kernel CSMain: plain path-trace mode, renderMode 1, and depth-aware temporal
- * reprojection, renderMode 2) plus progressive accumulation
+ * kernel CSMain: plain path-trace mode, renderMode 1; depth-aware temporal
+ * reprojection, renderMode 2; reprojection + a-trous denoiser + temporal
+ * anti-aliasing, renderMode 0) plus progressive accumulation
  * (Assets/Shaders/AddMat.shader), implemented as HIP kernels for gfx950.
  *
  * Each entry point replaces one call the reference's C# host
@@ -71,7 +72,8 @@ enum {
 enum {
     PT_TARGET_RESULT = 0,     /* "Result"  (RayTracingMaster.cs:740)  RGBA32F W*H */
     PT_TARGET_CONVERGED = 1,  /* "Result1" (RayTracingMaster.cs:741)  RGBA32F W*H */
-    PT_TARGET_HIT_IDS = 2     /* int32 W*H primary-hit ids; no counterpart in the reference (parity aid) */
+    PT_TARGET_HIT_IDS = 2,    /* int32 W*H primary-hit ids; no counterpart in the reference (parity aid) */
+    PT_TARGET_DENOISED = 3    /* "Result2" (RayTracingMaster.cs:743, denoisedTex)  RGBA32F W*H; renderMode 0 */
 };
 
 /* Per-dispatch uniforms: what SetShaderParameters() (RayTracingMaster.cs:455-540)
@@ -85,7 +87,7 @@ typedef struct PtFrameParams {
                                             (RayTracingShader.compute:866-873); must be >= 1     */
     int32_t depth;                       /* _Depth                    RayTracingMaster.cs:532     */
     int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735,977-990): 1 = Default,
-                                            2 = Reproj; the others are PT_ERR_UNSUPPORTED           */
+                                            2 = Reproj, 0 = Denoise; the others are PT_ERR_UNSUPPORTED */
     uint32_t sample_index;               /* _Sample of AddMat.shader:42 (RayTracingMaster.cs:805) */
     int32_t accumulate;                  /* PT_ACCUM_*                                            */
     int32_t tile_x0, tile_y0;            /* sub-rectangle of the image this dispatch renders;     */
@@ -188,7 +190,14 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
  * position is on screen and its stored distance agrees within 5 %.  The shader does that copy per
  * thread inside the same dispatch, so which of its threads see old or new history is a race there;
  * the whole-image copy is the ordering in which no thread sees another thread's new output.
- * accumulate must be PT_ACCUM_NONE (the converged target is the history). */
+ * accumulate must be PT_ACCUM_NONE (the converged target is the history).
+ *
+ * renderMode 0 (RayTracingShader.compute:733-736,885-930; the reference's start-up mode,
+ * RayTracingMaster.cs:991): Result1 first receives Result2 (the previous frame's accumulated radiance);
+ * the path tracer's reprojected radiance goes to Result2 (as renderMode 2 writes Result, plus the
+ * thread-group row limit of :908-915); then Result = denoiser(Result1) (:479-615) for every pixel, then
+ * Result = TAA(Result1, Result) (:644-714) for every pixel.  The shader runs all of it per thread without
+ * a barrier; here each step is complete before the next starts.  Whole frames only. */
 int pt_render(pt_context *ctx, const PtFrameParams *params);
 
 int pt_sync(pt_context *ctx);
@@ -198,6 +207,9 @@ int pt_sync(pt_context *ctx);
 int pt_read_result(pt_context *ctx, float *rgba_out);
 int pt_read_converged(pt_context *ctx, float *rgba_out);
 int pt_write_converged(pt_context *ctx, const float *rgba_in);
+/* The same for any RGBA target (PT_TARGET_RESULT / _CONVERGED / _DENOISED). */
+int pt_read_target(pt_context *ctx, int which, float *rgba_out);
+int pt_write_target(pt_context *ctx, int which, const float *rgba_in);
 int pt_read_hit_ids(pt_context *ctx, int32_t *ids_out);
 
 int pt_get_stats(pt_context *ctx, PtStats *out);

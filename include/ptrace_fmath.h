@@ -155,11 +155,19 @@ PT_FN float pt_exp2(float x)
     float s2 = pt_u2f((uint32_t)(n2 + 127) << 23);
     return (p * s1) * s2;
 }
+/* exp(x) = 2^(x * log2(e)); used by the denoiser weights (RayTracingShader.compute:578,612). */
+PT_FN float pt_exp(float x) { return pt_exp2(x * 0x1.715476p+0f); }
 PT_FN float pt_pow(float x, float y)
 {
     if (!(x > 0.0f)) return (y == 0.0f) ? 1.0f : 0.0f;
     return pt_exp2(y * pt_log2(x));
 }
+
+/* pow(x, 2.0) and pow(x, 0.5) with literal exponents (RayTracingShader.compute:626,641): the correctly
+ * rounded results x*x and sqrt(x) - what a shader compiler emits for these literals - with pt_pow's
+ * convention for x <= 0. */
+PT_FN float pt_pow_2(float x) { return (x > 0.0f) ? x * x : 0.0f; }
+PT_FN float pt_pow_half(float x) { return (x > 0.0f) ? pt_sqrt(x) : 0.0f; }
 
 /* ---- acos / atan2 ------------------------------------------------------ */
 PT_FN float pt__asin_poly(float z)

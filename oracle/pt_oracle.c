@@ -396,11 +396,135 @@ static void bilinear_texture_sample(const History *hs, int W, int H, float Px, f
     }
 }
 
+/* ---- renderMode 0: SH:466-615 (denoiser), SH:617-714 (TAA) ----
+ * Texture2D.Load / RWTexture2D.Load take int2: a float2 argument is truncated toward zero;
+ * operator[] takes uint2 (to_uint above).  Either way a location outside the texture reads 0. */
+static void load_int(const float *tex, int W, int H, float x, float y, float *out4)
+{
+    int ix = (x >= 2147483648.0f || x <= -2147483648.0f || x != x) ? -1 : (int)x;
+    int iy = (y >= 2147483648.0f || y <= -2147483648.0f || y != y) ? -1 : (int)y;
+    if (ix < 0 || iy < 0 || ix >= W || iy >= H) { out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; return; }
+    const float *q = tex + 4 * ((size_t)iy * W + ix);
+    for (int k = 0; k < 4; k++) out4[k] = q[k];
+}
+
+static float hash1(float seed) { return pt_frac(pt_sin(seed) * 43758.5453123f); }   /* SH:475-477 */
+
+static const float k_atrous[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};   /* SH:513-542 = outer product */
+
+/* denoiser(fragCoord), SH:479-615, on Result1; `seed` = _Seed at the time of the call. */
+static void denoiser(const float *result1, int W, int H, float fx, float fy, float seed, float *out4)
+{
+    const float c_phi = 1.0f, n_phi = 0.5f, p_phi = 0.25f;
+    float cv[4];
+    load_int(result1, W, H, fx, fy, cv);                                        /* SH:552 */
+    f3 cval = pt_make3(cv[0], cv[1], cv[2]);
+    float strength = 1.0f + (4.0f - 1.0f) * hash1((641.128752f * fx + 312.321374f * fy) + 1.92357812f * seed);  /* SH:564 */
+    f3 sum = pt_make3(0, 0, 0), sum_f = pt_make3(0, 0, 0);
+    float cum_w = 0.0f, cum_fw = 0.0f;
+    for (int i = 0; i < 25; i++) {
+        float ox = (float)(i % 5 - 2), oy = (float)(i / 5 - 2);                 /* SH:481-510 */
+        float kern = k_atrous[i % 5] * k_atrous[i / 5];
+        float tv[4];
+        load_int(result1, W, H, fx + ox * strength, fy + oy * strength, tv);    /* SH:572-575 */
+        f3 ctmp = pt_make3(tv[0], tv[1], tv[2]);
+        f3 t = pt_sub3(cval, ctmp);
+        float dist2 = pt_dot3(t, t);
+        float c_w = pt_min(pt_exp(-(dist2) / c_phi), 1.0f);                     /* SH:578 */
+        float n_w = pt_min(pt_exp(-(0.0f) / n_phi), 1.0f);                      /* SH:592 */
+        float r_w = c_w;                                                        /* SH:593 */
+        float weight0 = c_w * n_w;
+        sum.x += ctmp.x * weight0 * kern; sum.y += ctmp.y * weight0 * kern; sum.z += ctmp.z * weight0 * kern;   /* SH:597 */
+        cum_w += weight0 * kern;
+        float weight1 = r_w * n_w;
+        sum_f.x += ctmp.x * weight1 * kern; sum_f.y += ctmp.y * weight1 * kern; sum_f.z += ctmp.z * weight1 * kern;
+        cum_fw += weight1 * kern;
+    }
+    f3 a = pt_make3(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w);
+    f3 b = pt_make3(sum_f.x / cum_fw, sum_f.y / cum_fw, sum_f.z / cum_fw);
+    float dist2 = pt_dot3(a, a);                                                /* SH:608-611 with ptmp = 0 */
+    float p_w = pt_min(pt_exp(-(dist2) / p_phi), 1.0f);
+    out4[0] = pt_min(pt_max(a.x + p_w * (b.x - a.x), 0.0f), 1.0f);              /* SH:614 */
+    out4[1] = pt_min(pt_max(a.y + p_w * (b.y - a.y), 0.0f), 1.0f);
+    out4[2] = pt_min(pt_max(a.z + p_w * (b.z - a.z), 0.0f), 1.0f);
+    out4[3] = 0.0f;
+}
+
+static f3 encode_pal_yuv(f3 rgb)                                                 /* SH:624-632 */
+{
+    rgb = pt_make3(pt_pow_2(rgb.x), pt_pow_2(rgb.y), pt_pow_2(rgb.z));
+    return pt_make3(pt_dot3(rgb, pt_make3(0.299f, 0.587f, 0.114f)),
+                    pt_dot3(rgb, pt_make3(-0.14713f, -0.28886f, 0.436f)),
+                    pt_dot3(rgb, pt_make3(0.615f, -0.51499f, -0.10001f)));
+}
+
+static f3 decode_pal_yuv(f3 yuv)                                                 /* SH:634-642 */
+{
+    f3 rgb = pt_make3(pt_dot3(yuv, pt_make3(1.0f, 0.0f, 1.13983f)),
+                      pt_dot3(yuv, pt_make3(1.0f, -0.39465f, -0.58060f)),
+                      pt_dot3(yuv, pt_make3(1.0f, 2.03211f, 0.0f)));
+    return pt_make3(pt_pow_half(rgb.x), pt_pow_half(rgb.y), pt_pow_half(rgb.z));
+}
+
+static f3 min3v(f3 a, f3 b) { return pt_make3(pt_min(a.x, b.x), pt_min(a.y, b.y), pt_min(a.z, b.z)); }
+static f3 max3v(f3 a, f3 b) { return pt_make3(pt_max(a.x, b.x), pt_max(a.y, b.y), pt_max(a.z, b.z)); }
+static f3 lerp3(f3 a, f3 b, float t) { return pt_make3(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z)); }
+
+static f3 load_xyz_uint(const float *tex, int W, int H, float x, float y)        /* tex[float2]: operator[] */
+{
+    History hs = {NULL, tex};
+    float v[4];
+    load_result1(&hs, W, H, x, y, v);
+    return pt_make3(v[0], v[1], v[2]);
+}
+
+/* TAA(fragCoord), SH:644-714: history from Result1, current frame and its neighbours from `cur`
+ * (the denoised image of every pixel - the shader reads Result while other threads are still
+ * writing it; here all of them have finished the denoiser and none has written the TAA output). */
+static void taa(const float *result1, const float *cur, int W, int H, float fx, float fy, float *out4)
+{
+    History hs = {NULL, result1};
+    float last[4];
+    bilinear_texture_sample(&hs, W, H, fx, fy, last);                           /* SH:651 */
+    f3 antialiased = pt_make3(last[0], last[1], last[2]);
+    float mixRate = 0.5f;
+    float offx = 1.0f / (float)W, offy = 1.0f / (float)H;                        /* SH:657 */
+    f3 in0 = load_xyz_uint(cur, W, H, fx, fy);                                   /* SH:659 */
+    antialiased = lerp3(pt_make3(antialiased.x * antialiased.x, antialiased.y * antialiased.y, antialiased.z * antialiased.z),
+                        pt_make3(in0.x * in0.x, in0.y * in0.y, in0.z * in0.z), mixRate);   /* SH:661 */
+    antialiased = pt_make3(pt_sqrt(antialiased.x), pt_sqrt(antialiased.y), pt_sqrt(antialiased.z));
+    f3 in1 = load_xyz_uint(cur, W, H, fx + offx, fy + 0.0f);                     /* SH:673-680 */
+    f3 in2 = load_xyz_uint(cur, W, H, fx + -offx, fy + 0.0f);
+    f3 in3 = load_xyz_uint(cur, W, H, fx + 0.0f, fy + offy);
+    f3 in4 = load_xyz_uint(cur, W, H, fx + 0.0f, fy + -offy);
+    f3 in5 = load_xyz_uint(cur, W, H, fx + offx, fy + offy);
+    f3 in6 = load_xyz_uint(cur, W, H, fx + -offx, fy + offy);
+    f3 in7 = load_xyz_uint(cur, W, H, fx + offx, fy + -offy);
+    f3 in8 = load_xyz_uint(cur, W, H, fx + -offx, fy + -offy);
+    antialiased = encode_pal_yuv(antialiased);
+    in0 = encode_pal_yuv(in0); in1 = encode_pal_yuv(in1); in2 = encode_pal_yuv(in2); in3 = encode_pal_yuv(in3);
+    in4 = encode_pal_yuv(in4); in5 = encode_pal_yuv(in5); in6 = encode_pal_yuv(in6); in7 = encode_pal_yuv(in7);
+    in8 = encode_pal_yuv(in8);
+    f3 minColor = min3v(min3v(min3v(in0, in1), min3v(in2, in3)), in4);           /* SH:693-698 */
+    f3 maxColor = max3v(max3v(max3v(in0, in1), max3v(in2, in3)), in4);
+    minColor = lerp3(minColor, min3v(min3v(min3v(in5, in6), min3v(in7, in8)), minColor), 0.5f);
+    maxColor = lerp3(maxColor, max3v(max3v(max3v(in5, in6), max3v(in7, in8)), maxColor), 0.5f);
+    f3 preclamping = antialiased;
+    antialiased = min3v(max3v(antialiased, minColor), maxColor);                 /* clamp(x, lo, hi) = min(max(x, lo), hi) */
+    mixRate = 1.0f / (1.0f / mixRate + 1.0f);                                    /* SH:703 */
+    f3 diff = pt_sub3(antialiased, preclamping);
+    float clampAmount = pt_dot3(diff, diff);
+    mixRate += clampAmount * 4.0f;
+    mixRate = pt_min(pt_max(mixRate, 0.05f), 0.5f);
+    antialiased = decode_pal_yuv(antialiased);
+    out4[0] = antialiased.x; out4[1] = antialiased.y; out4[2] = antialiased.z; out4[3] = mixRate;   /* SH:713 */
+}
+
 /* CSMain for one thread id, renderMode 1 or 2: SH:798-809, SH:822-874, SH:933-936, SH:950-983.
  * The prologue copy Result1 = Result (SH:728-731) is done for the whole rectangle by the caller
  * before any pixel runs; `hs` is NULL in renderMode 1. */
 static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, int idx, int idy,
-                    float *out4, int32_t *hit_id, Counters *cn, const History *hs)
+                    float *out4, int32_t *hit_id, Counters *cn, const History *hs, float *seed_out)
 {
     float fw = (float)W, fh = (float)H;
     float u = (float)idx / fw * 2.0f - 1.0f;   /* SH:802, SH:842: pixel corner, no jitter */
@@ -420,7 +544,7 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
     float fspp = (float)spp;
     int maxb = prm->max_bounces;
     f3 camo = pt_make3(prm->camera_to_world[12], prm->camera_to_world[13], prm->camera_to_world[14]);
-    out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; /* spp <= 0: the shader writes nothing; targets start zeroed */
+    if (prm->render_mode == 1) out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; /* spp <= 0: the shader writes nothing; targets start zeroed */
     for (int j = 1; j < spp + 1; j++) {            /* SH:839 */
         Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
         cn->paths++;
@@ -442,7 +566,8 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
             result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
             if (!any3(ray.energy)) break;          /* SH:871 */
         }
-        if (prm->render_mode == 2 && hs) {         /* SH:950-983 */
+        if (seed_out) *seed_out = rs.seed;         /* _Seed as the denoiser's hash will see it (SH:564) */
+        if ((prm->render_mode == 2 || prm->render_mode == 0) && hs) {   /* SH:950-983; SH:885-925 writes Result2 the same way */
             f3 origin = camo;
             f3 originOld = pt_make3(hs->cam->camera_to_world[12], hs->cam->camera_to_world[13], hs->cam->camera_to_world[14]);
             float reproUV[2];
@@ -457,12 +582,16 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
                 load_result1(hs, W, H, reproUV[0], reproUV[1], direct);
                 take = (pt_abs(distOld - bl[3]) < distOld * 0.05f || direct[3] > 80.0f) && !primary_miss;
             }
-            if (take) {                            /* SH:973 */
+            if (take && prm->render_mode == 0) {   /* SH:908-915: history only from rows above the end of this thread group */
+                float maximum = pt_floor((float)idy / 32.0f) * 32.0f + 32.0f;
+                if (!(reproUV[1] < maximum)) take = 0;
+            }
+            if (take) {                            /* SH:973, SH:912 */
                 out4[0] = (bl[0] * (divisor - 1.0f)) / divisor + result.x / divisor;
                 out4[1] = (bl[1] * (divisor - 1.0f)) / divisor + result.y / divisor;
                 out4[2] = (bl[2] * (divisor - 1.0f)) / divisor + result.z / divisor;
                 out4[3] = distOld;
-            } else {                               /* SH:981 */
+            } else {                               /* SH:981, SH:914, SH:924 */
                 out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
                 out4[3] = pt_length3(pt_sub3(hitPos, origin));
             }
@@ -478,34 +607,65 @@ int pto_render(const PtoPrepared *p, const PtFrameParams *prm, int W, int H,
                float *result, int32_t *hit_ids, PtoStats *stats, int threads)
 {
     if (prm && prm->render_mode != 1) return 1;
-    return pto_render_history(p, prm, NULL, 0, W, H, result, NULL, hit_ids, stats, threads);
+    return pto_render_history(p, prm, NULL, 0, W, H, result, NULL, NULL, hit_ids, stats, threads);
 }
 
 int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtCameraHistory *history, int n_history,
-                       int W, int H, float *result, float *result1, int32_t *hit_ids, PtoStats *stats, int threads)
+                       int W, int H, float *result, float *result1, float *result2, int32_t *hit_ids, PtoStats *stats,
+                       int threads)
 {
     if (!p || !prm || !result || W <= 0 || H <= 0 || prm->max_bounces < 1) return 1;
-    if (prm->render_mode != 1 && prm->render_mode != 2) return 1;
-    if (prm->render_mode == 2 && !result1) return 1;
+    const int mode = prm->render_mode;
+    if (mode != 0 && mode != 1 && mode != 2) return 1;
+    if (mode != 1 && !result1) return 1;
+    if (mode == 0 && !result2) return 1;
     PtCameraHistory zero;
     memset(&zero, 0, sizeof zero);               /* uniform arrays never uploaded hold zeros */
     History hs = {n_history > 0 && history ? &history[0] : &zero, result1};
     int x0 = 0, y0 = 0, tw = W, th = H;
     if (prm->tile_w > 0 && prm->tile_h > 0) { x0 = prm->tile_x0; y0 = prm->tile_y0; tw = prm->tile_w; th = prm->tile_h; }
     if (x0 < 0 || y0 < 0 || x0 + tw > W || y0 + th > H) return 1;
+    if (mode == 0 && (tw != W || th != H)) return 1;   /* the denoiser and TAA read neighbours: whole frames only */
     if (threads <= 0) threads = 1;
-    if (prm->render_mode == 2 && prm->depth != 1)    /* SH:728-731 for every dispatched thread, before any of them goes on */
+    const int screen_passes = mode == 0 && prm->depth != 1 && prm->samples_per_pixel > 0;
+    /* SH:728-736 for every dispatched thread, before any of them goes on:
+     * Result1 = Result (renderMode 2) or Result1 = Result2 (renderMode 0) */
+    if (mode != 1) {
+        const float *src = mode == 0 ? result2 : result;
         for (int y = y0; y < y0 + th; y++)
-            memcpy(result1 + 4 * ((size_t)y * W + x0), result + 4 * ((size_t)y * W + x0), (size_t)tw * 4 * sizeof(float));
+            memcpy(result1 + 4 * ((size_t)y * W + x0), src + 4 * ((size_t)y * W + x0), (size_t)tw * 4 * sizeof(float));
+    }
+    float *seeds = NULL, *denoised = NULL;
+    if (screen_passes) {
+        seeds = (float *)malloc((size_t)W * H * sizeof(float));
+        denoised = (float *)malloc((size_t)W * H * 4 * sizeof(float));
+        if (!seeds || !denoised) { free(seeds); free(denoised); return 1; }
+    }
+    /* the path tracer; renderMode 0 writes its (reprojected) radiance to Result2, SH:912-924 */
+    float *trace_out = (mode == 0 && prm->depth != 1) ? result2 : result;
     uint64_t a = 0, b = 0, c = 0, d = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a, b, c, d)
     for (int y = y0; y < y0 + th; y++) {
         Counters cn = {0, 0, 0, 0, NULL, 0, 0};
         for (int x = x0; x < x0 + tw; x++) {
             size_t px = (size_t)y * W + x;
-            cs_main(p, prm, W, H, x, y, result + 4 * px, hit_ids ? hit_ids + px : NULL, &cn, &hs);
+            cs_main(p, prm, W, H, x, y, trace_out + 4 * px, hit_ids ? hit_ids + px : NULL, &cn, &hs, seeds ? seeds + px : NULL);
         }
         a += cn.trace_calls; b += cn.rays; c += cn.paths; d += cn.prims;
+    }
+    if (screen_passes) {
+        /* SH:928: Result = denoiser(id) for every pixel, then SH:929: Result = TAA(id) for every pixel */
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                size_t px = (size_t)y * W + x;
+                denoiser(result1, W, H, (float)x, (float)y, seeds[px], denoised + 4 * px);
+            }
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                taa(result1, denoised, W, H, (float)x, (float)y, result + 4 * ((size_t)y * W + x));
+        free(seeds); free(denoised);
     }
     if (stats) { stats->trace_calls = a; stats->rays = b; stats->paths = c; stats->prims_tested = d; }
     return 0;
@@ -687,7 +847,7 @@ int pto_path_dump(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, 
 {
     Counters cn = {0, 0, 0, 0, log, cap, 0};
     float out4[4]; int32_t id;
-    cs_main(p, prm, W, H, idx, idy, out4, &id, &cn, NULL);
+    cs_main(p, prm, W, H, idx, idy, out4, &id, &cn, NULL, NULL);
     return cn.log_n;
 }
 
@@ -703,6 +863,9 @@ void pto_bilinear_sample(const float *result1, int W, int H, float px, float py,
     bilinear_texture_sample(&hs, W, H, px, py, out4);
 }
 
+void pto_denoiser(const float *result1, int W, int H, int x, int y, float seed, float *out4) { denoiser(result1, W, H, (float)x, (float)y, seed, out4); }
+void pto_taa(const float *result1, const float *current, int W, int H, int x, int y, float *out4) { taa(result1, current, W, H, (float)x, (float)y, out4); }
+
 float pto_fmath(int which, float a, float b)
 {
     switch (which) {
@@ -713,6 +876,8 @@ float pto_fmath(int which, float a, float b)
     case 4: return pt_atan2(a, b);
     case 5: return pt_log2(a);
     case 6: return pt_exp2(a);
+    case 7: return pt_exp(a);
+    case 8: return pt_frac(a);
     default: return 0.0f;
     }
 }

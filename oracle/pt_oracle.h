@@ -1,8 +1,8 @@
 /*
  * pt_oracle.h - CPU oracle for libptrace.  TEST INFRASTRUCTURE ONLY.
  *
- * A scalar restatement, in plain C, of the plain path-trace mode and the
- * temporal-reprojection mode (renderMode 1 and 2) of
+ * A scalar restatement, in plain C, of the plain path-trace mode, the
+ * temporal-reprojection mode and the denoise mode (renderMode 1, 2 and 0) of
  * Assets/Scripts/RayTracingShader.compute (kernel CSMain) and of
  * Assets/Shaders/AddMat.shader, written line by line from those files.  It is
  * the checker the HIP kernels are compared with; nothing in the product links
@@ -57,13 +57,20 @@ void pto_release(PtoPrepared *p);
 int pto_render(const PtoPrepared *p, const PtFrameParams *params, int width, int height,
                float *result, int32_t *hit_ids, PtoStats *stats, int threads);
 
-/* The same for renderMode 1 or 2.  renderMode 2 (RayTracingShader.compute:728-731,950-983):
- * `result` holds the previous frame on entry; `result1` (W*H*4) first receives a copy of it over the
- * dispatched rectangle - the whole copy before any pixel is traced - and is the history the pixels
- * reproject from; history[0] is entry 0 of the four *Old camera arrays (zeros when n_history == 0). */
+/* The same for renderMode 0, 1 or 2.
+ * renderMode 2 (RayTracingShader.compute:728-731,950-983): `result` holds the previous frame on entry;
+ * `result1` (W*H*4) first receives a copy of it over the dispatched rectangle - the whole copy before any
+ * pixel is traced - and is the history the pixels reproject from; history[0] is entry 0 of the four *Old
+ * camera arrays (zeros when n_history == 0).
+ * renderMode 0 (:733-736,885-930): `result1` first receives `result2` (the accumulated radiance of the
+ * previous frame); the traced, reprojected radiance of every pixel goes to `result2`; then every pixel of
+ * `result` = denoiser(Result1) (:479-615), then every pixel of `result` = TAA (:644-714) of Result1 and the
+ * denoised image.  Whole frames only.  The shader runs these steps per thread without any barrier, so
+ * which neighbours a thread sees finished is a race there; this is the ordering in which every step is
+ * complete before the next one starts. */
 int pto_render_history(const PtoPrepared *p, const PtFrameParams *params, const PtCameraHistory *history, int n_history,
-                       int width, int height, float *result, float *result1, int32_t *hit_ids, PtoStats *stats,
-                       int threads);
+                       int width, int height, float *result, float *result1, float *result2, int32_t *hit_ids,
+                       PtoStats *stats, int threads);
 
 /* AddMat.shader / running mean / sum: same modes as PtFrameParams.accumulate. */
 void pto_accumulate(int mode, uint32_t sample_index, const float *fresh, float *converged, int64_t n_pixels);
@@ -79,7 +86,9 @@ int pto_path_dump(const PtoPrepared *p, const PtFrameParams *params, int width, 
                   float *log8, int capacity);
 void pto_find_camera_ray(const PtCameraHistory *old_camera, int width, int height, const float *dir3, float *uv2); /* SH:394-411 */
 void pto_bilinear_sample(const float *result1, int width, int height, float px, float py, float *out4);            /* SH:440-463 */
-float pto_fmath(int which, float a, float b); /* 0 sin 1 cos 2 pow 3 acos 4 atan2 5 log2 6 exp2 */
+void pto_denoiser(const float *result1, int width, int height, int x, int y, float seed, float *out4);             /* SH:479-615 */
+void pto_taa(const float *result1, const float *current, int width, int height, int x, int y, float *out4);        /* SH:644-714 */
+float pto_fmath(int which, float a, float b); /* 0 sin 1 cos 2 pow 3 acos 4 atan2 5 log2 6 exp2 7 exp 8 frac */
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,9 @@ def lib():
                                  C.POINTER(PtoStats), C.c_int]
         L.pto_render_history.restype = C.c_int
         L.pto_render_history.argtypes = [C.c_void_p, C.POINTER(PtFrameParams), C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PtoStats), C.c_int]
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PtoStats), C.c_int]
+        L.pto_denoiser.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.pto_taa.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pto_accumulate.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64]
         L.pto_rand_sequence.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pto_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -104,15 +106,18 @@ class Oracle:
             raise ValueError("pto_render: bad arguments")
         return img, ids, {k: getattr(st, k) for k, _ in PtoStats._fields_}
 
-    def render_history(self, params, history, width, height, result, result1, threads=1):
-        """renderMode 1 or 2 with the camera history `history` (list of PtCameraHistory).  `result` (previous frame on
-        entry, new frame on return) and `result1` (the history image) are (H, W, 4) float32 arrays updated in place."""
-        assert result.dtype == np.float32 and result1.dtype == np.float32 and result.flags.c_contiguous and result1.flags.c_contiguous
+    def render_history(self, params, history, width, height, result, result1, threads=1, result2=None):
+        """renderMode 0, 1 or 2 with the camera history `history` (list of PtCameraHistory).  `result` (previous frame on
+        entry, new frame on return), `result1` (the history image) and, for renderMode 0, `result2` (the accumulated
+        radiance) are (H, W, 4) float32 arrays updated in place."""
+        for a in (result, result1) + ((result2,) if result2 is not None else ()):
+            assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == (height, width, 4)
         ids = np.full((height, width), -1, np.int32)
         st = PtoStats()
         arr = (PtCameraHistory * max(1, len(history)))(*history)
         rc = lib().pto_render_history(self._p, C.byref(params), C.byref(arr), len(history), width, height, result.ctypes.data,
-                                      result1.ctypes.data, ids.ctypes.data, C.byref(st), threads)
+                                      result1.ctypes.data, result2.ctypes.data if result2 is not None else None,
+                                      ids.ctypes.data, C.byref(st), threads)
         if rc != 0:
             raise ValueError("pto_render_history: bad arguments")
         return ids, {k: getattr(st, k) for k, _ in PtoStats._fields_}
@@ -157,7 +162,7 @@ def camera_ray(c2w, ip, idx, idy, w, h):
 
 
 def fmath(which, a, b=0.0):
-    return float(lib().pto_fmath({"sin": 0, "cos": 1, "pow": 2, "acos": 3, "atan2": 4, "log2": 5, "exp2": 6}[which], a, b))
+    return float(lib().pto_fmath({"sin": 0, "cos": 1, "pow": 2, "acos": 3, "atan2": 4, "log2": 5, "exp2": 6, "exp": 7, "frac": 8}[which], a, b))
 
 
 def find_camera_ray(old_camera, width, height, direction):
@@ -169,4 +174,16 @@ def find_camera_ray(old_camera, width, height, direction):
 def bilinear_sample(result1, px, py):
     img = np.ascontiguousarray(result1, np.float32); out = np.zeros(4, np.float32)
     lib().pto_bilinear_sample(img.ctypes.data, img.shape[1], img.shape[0], px, py, out.ctypes.data)
+    return out
+
+
+def denoiser(result1, x, y, seed):
+    img = np.ascontiguousarray(result1, np.float32); out = np.zeros(4, np.float32)
+    lib().pto_denoiser(img.ctypes.data, img.shape[1], img.shape[0], x, y, seed, out.ctypes.data)
+    return out
+
+
+def taa(result1, current, x, y):
+    a = np.ascontiguousarray(result1, np.float32); b = np.ascontiguousarray(current, np.float32); out = np.zeros(4, np.float32)
+    lib().pto_taa(a.ctypes.data, b.ctypes.data, a.shape[1], a.shape[0], x, y, out.ctypes.data)
     return out

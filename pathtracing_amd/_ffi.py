@@ -43,7 +43,7 @@ class PtStats(C.Structure):
 assert C.sizeof(PtSphere) == 56 and C.sizeof(PtMeshObject) == 72
 
 PT_ACCUM_NONE, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_ACCUM_ADDMAT = 0, 1, 2, 3
-PT_TARGET_RESULT, PT_TARGET_CONVERGED, PT_TARGET_HIT_IDS = 0, 1, 2
+PT_TARGET_RESULT, PT_TARGET_CONVERGED, PT_TARGET_HIT_IDS, PT_TARGET_DENOISED = 0, 1, 2, 3
 
 _P = C.POINTER
 _ctx = C.c_void_p
@@ -67,6 +67,8 @@ PTRACE_SYMBOLS = {
     "pt_read_result": (C.c_int, [_ctx, C.c_void_p]),
     "pt_read_converged": (C.c_int, [_ctx, C.c_void_p]),
     "pt_write_converged": (C.c_int, [_ctx, C.c_void_p]),
+    "pt_read_target": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "pt_write_target": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "pt_read_hit_ids": (C.c_int, [_ctx, C.c_void_p]),
     "pt_get_stats": (C.c_int, [_ctx, _P(PtStats)]),
     "pt_trace_rays": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -71,7 +71,11 @@ struct RenderArgs {
     float old_c2w[16];            // _CameraToWorldOld[0]
     float old_w2c[16];            // _WorldToCameraOld[0]
     float old_proj[16];           // _CameraProjectionOld[0]
-    const float4 *history;        // Result1: the previous frame's Result
+    const float4 *history;        // Result1: the previous frame's Result (renderMode 2) or Result2 (renderMode 0)
+    // renderMode 0 (SH:885-925): the reprojected radiance goes to Result2, and the pixel's running _Seed is kept
+    // for the denoiser's hash (SH:564)
+    float4 *result2;
+    float *seed_out;
 };
 
 constexpr int kBlock = 256;            // 4 waves
@@ -535,8 +539,8 @@ __device__ __forceinline__ float4 bilinear_history(const RenderArgs &a, f2 P)
     return make_float4(lerp1(x1.x, x2.x, fy), lerp1(x1.y, x2.y, fy), lerp1(x1.z, x2.z, fy), lerp1(x1.w, x2.w, fy));
 }
 
-// SH:953-982: the value renderMode 2 writes for a finished pixel.
-__device__ __forceinline__ float4 reproject_pixel(const RenderArgs &a, f3 result, f3 hit_pos, bool sky, float alpha_dist)
+// SH:953-982 / SH:888-925: the value renderMode 2 writes to Result, renderMode 0 to Result2, for a finished pixel.
+__device__ __forceinline__ float4 reproject_pixel(const RenderArgs &a, f3 result, f3 hit_pos, bool sky, float alpha_dist, int pix_y)
 {
     const f3 origin_old = pt_make3(a.old_c2w[12], a.old_c2w[13], a.old_c2w[14]);
     const f3 to_hit = pt_sub3(hit_pos, origin_old);
@@ -546,7 +550,10 @@ __device__ __forceinline__ float4 reproject_pixel(const RenderArgs &a, f3 result
         const float4 bl = bilinear_history(a, uv);
         const float dist_old = pt_length3(to_hit);
         const float direct_w = history_load(a, uv.x, uv.y).w;
-        if ((pt_abs(dist_old - bl.w) < dist_old * 0.05f || direct_w > 80.0f) && !sky)
+        bool take = (pt_abs(dist_old - bl.w) < dist_old * 0.05f || direct_w > 80.0f) && !sky;
+        // SH:908-915 (renderMode 0): history only from rows above the end of the pixel's 32-row thread group
+        if (a.render_mode == 0 && !(uv.y < pt_floor((float)pix_y / 32.0f) * 32.0f + 32.0f)) take = false;
+        if (take)
             return make_float4(bl.x * (divisor - 1.0f) / divisor + result.x / divisor,
                                bl.y * (divisor - 1.0f) / divisor + result.y / divisor,
                                bl.z * (divisor - 1.0f) / divisor + result.z / divisor, dist_old);
@@ -730,8 +737,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                             const f3 hit_pos0 = sky ? pt_make3(0, 0, 0) : pt_along3(co, t_primary, cd);
                             const float alpha_dist = pt_length3(pt_sub3(hit_pos0, co));
                             float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
-                            if (a.render_mode == 2) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist);
-                            a.result[p] = fresh;
+                            if (a.render_mode != 1) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist, pix_y);
+                            if (a.render_mode == 0) { a.result2[p] = fresh; a.seed_out[p] = rs.seed; }
+                            else a.result[p] = fresh;
                             if (a.hit_ids) a.hit_ids[p] = primary_id;
                             accumulate_pixel(a, p, fresh);
                             finished = true;

@@ -1,0 +1,145 @@
+// Screen-space passes of renderMode 0 (RenderMode.Denoise): the edge-avoiding a-trous filter
+// (SH:466-615) and the temporal anti-aliasing resolve (SH:617-714) of
+// Assets/Scripts/RayTracingShader.compute, one thread per pixel.
+//
+// In the shader both run at the end of CSMain, per thread, with no barrier between them
+// (SH:928-929): TAA() reads the `Result` texels of neighbouring threads that may or may not have
+// written their denoiser() output yet.  Here the two are separate launches: the filter writes every
+// pixel of a scratch image, then the resolve reads that image and writes `Result`, so every thread
+// sees its neighbours' filtered value and nobody's resolved one.
+//
+// Both kernels stream: per pixel the filter reads 25 history texels that lie within +-8 pixels of it
+// (served by L1/L2: algorithmic traffic is one 16-byte read and one 16-byte write per pixel) and the
+// resolve reads 4 history texels, 4 filtered texels and writes one (48 bytes per pixel).
+#pragma once
+
+#include "pt_device.hpp"
+
+namespace ptrace {
+
+struct ScreenArgs {
+    const float4 *history;    // Result1
+    const float *seeds;       // _Seed of every pixel after its last sample (SH:564 reads the running counter)
+    float4 *filtered;         // scratch: denoiser() of every pixel
+    float4 *result;           // Result
+    int32_t W, H;
+};
+
+// Texture2D.Load(int2): a float2 location is truncated toward zero; outside the texture reads 0.
+__device__ __forceinline__ float4 load_trunc_int(const float4 *tex, int W, int H, float x, float y)
+{
+    const bool bad = !(x > -2147483648.0f && x < 2147483648.0f && y > -2147483648.0f && y < 2147483648.0f);
+    const int ix = bad ? -1 : (int)x, iy = bad ? -1 : (int)y;
+    if (ix < 0 || iy < 0 || ix >= W || iy >= H) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return tex[(size_t)iy * W + ix];
+}
+
+// tex[float2] (operator[] takes uint2): truncation, negative and NaN to 0; outside reads 0.
+__device__ __forceinline__ float4 load_trunc_uint(const float4 *tex, int W, int H, float x, float y)
+{
+    const uint32_t ix = hlsl_ftou(x), iy = hlsl_ftou(y);
+    if (ix >= (uint32_t)W || iy >= (uint32_t)H) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return tex[(size_t)iy * W + ix];
+}
+
+__device__ __forceinline__ float hash1(float seed) { return pt_frac(pt_sin(seed) * 43758.5453123f); }   // SH:475-477
+
+constexpr int kScreenBlockX = 64, kScreenBlockY = 4;
+
+// denoiser(fragCoord), SH:479-615.  The 25 weights of SH:513-542 are the outer product of
+// (1/16, 1/4, 3/8, 1/4, 1/16) with itself; all products are exact in binary32.
+__global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void denoise_kernel(const ScreenArgs a)
+{
+    const int x = blockIdx.x * kScreenBlockX + threadIdx.x, y = blockIdx.y * kScreenBlockY + threadIdx.y;
+    if (x >= a.W || y >= a.H) return;
+    const size_t p = (size_t)y * a.W + x;
+    const float fx = (float)x, fy = (float)y;
+    const float c_phi = 1.0f, n_phi = 0.5f, p_phi = 0.25f;
+    const float4 c4 = load_trunc_int(a.history, a.W, a.H, fx, fy);                          // SH:552
+    const f3 cval = pt_make3(c4.x, c4.y, c4.z);
+    const float strength = 1.0f + (4.0f - 1.0f) * hash1((641.128752f * fx + 312.321374f * fy) + 1.92357812f * a.seeds[p]);   // SH:564
+    const float n_w = pt_min(pt_exp(-(0.0f) / n_phi), 1.0f);                                // SH:592
+    f3 sum = pt_make3(0, 0, 0), sum_f = pt_make3(0, 0, 0);
+    float cum_w = 0.0f, cum_fw = 0.0f;
+    const float kw[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const float kern = kw[i] * kw[j];
+            const float4 t4 = load_trunc_int(a.history, a.W, a.H, fx + (float)(i - 2) * strength, fy + (float)(j - 2) * strength);   // SH:572-575
+            const f3 ctmp = pt_make3(t4.x, t4.y, t4.z);
+            const f3 t = pt_sub3(cval, ctmp);
+            const float dist2 = pt_dot3(t, t);
+            const float c_w = pt_min(pt_exp(-(dist2) / c_phi), 1.0f);                        // SH:578
+            const float r_w = c_w;                                                          // SH:593
+            const float weight0 = c_w * n_w;
+            sum.x += ctmp.x * weight0 * kern; sum.y += ctmp.y * weight0 * kern; sum.z += ctmp.z * weight0 * kern;   // SH:597-598
+            cum_w += weight0 * kern;
+            const float weight1 = r_w * n_w;
+            sum_f.x += ctmp.x * weight1 * kern; sum_f.y += ctmp.y * weight1 * kern; sum_f.z += ctmp.z * weight1 * kern;
+            cum_fw += weight1 * kern;
+        }
+    }
+    const f3 u = pt_make3(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w);
+    const f3 v = pt_make3(sum_f.x / cum_fw, sum_f.y / cum_fw, sum_f.z / cum_fw);
+    const float p_w = pt_min(pt_exp(-(pt_dot3(u, u)) / p_phi), 1.0f);                       // SH:608-612, ptmp = 0
+    a.filtered[p] = make_float4(pt_min(pt_max(lerp1(u.x, v.x, p_w), 0.0f), 1.0f), pt_min(pt_max(lerp1(u.y, v.y, p_w), 0.0f), 1.0f),
+                                pt_min(pt_max(lerp1(u.z, v.z, p_w), 0.0f), 1.0f), 0.0f);    // SH:614
+}
+
+__device__ __forceinline__ f3 encode_pal_yuv(f3 rgb)   // SH:624-632
+{
+    rgb = pt_make3(pt_pow_2(rgb.x), pt_pow_2(rgb.y), pt_pow_2(rgb.z));
+    return pt_make3(pt_dot3(rgb, pt_make3(0.299f, 0.587f, 0.114f)), pt_dot3(rgb, pt_make3(-0.14713f, -0.28886f, 0.436f)),
+                    pt_dot3(rgb, pt_make3(0.615f, -0.51499f, -0.10001f)));
+}
+__device__ __forceinline__ f3 decode_pal_yuv(f3 yuv)   // SH:634-642
+{
+    const f3 rgb = pt_make3(pt_dot3(yuv, pt_make3(1.0f, 0.0f, 1.13983f)), pt_dot3(yuv, pt_make3(1.0f, -0.39465f, -0.58060f)),
+                            pt_dot3(yuv, pt_make3(1.0f, 2.03211f, 0.0f)));
+    return pt_make3(pt_pow_half(rgb.x), pt_pow_half(rgb.y), pt_pow_half(rgb.z));
+}
+__device__ __forceinline__ f3 vmin3(f3 a, f3 b) { return pt_make3(pt_min(a.x, b.x), pt_min(a.y, b.y), pt_min(a.z, b.z)); }
+__device__ __forceinline__ f3 vmax3(f3 a, f3 b) { return pt_make3(pt_max(a.x, b.x), pt_max(a.y, b.y), pt_max(a.z, b.z)); }
+__device__ __forceinline__ f3 vlerp3(f3 a, f3 b, float t) { return pt_make3(lerp1(a.x, b.x, t), lerp1(a.y, b.y, t), lerp1(a.z, b.z, t)); }
+
+// TAA(fragCoord), SH:644-714.  The eight neighbour reads of SH:673-680 offset the pixel position by
+// 1/textureSize, so after index truncation they land on the pixel itself (+) or its left / upper
+// neighbour (-); the arithmetic is kept as written so that sizes where 1/W vanishes behave alike.
+__global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void taa_kernel(const ScreenArgs a, const RenderArgs ra)
+{
+    const int x = blockIdx.x * kScreenBlockX + threadIdx.x, y = blockIdx.y * kScreenBlockY + threadIdx.y;
+    if (x >= a.W || y >= a.H) return;
+    const float fx = (float)x, fy = (float)y;
+    f2 uv; uv.x = fx; uv.y = fy;
+    const float4 last = bilinear_history(ra, uv);                                            // SH:651
+    f3 aa = pt_make3(last.x, last.y, last.z);
+    float mixRate = 0.5f;
+    const float offx = 1.0f / (float)a.W, offy = 1.0f / (float)a.H;                          // SH:657
+    auto cur = [&](float px, float py) { const float4 q = load_trunc_uint(a.filtered, a.W, a.H, px, py); return pt_make3(q.x, q.y, q.z); };
+    f3 in0 = cur(fx, fy);                                                                    // SH:659
+    aa = vlerp3(pt_make3(aa.x * aa.x, aa.y * aa.y, aa.z * aa.z), pt_make3(in0.x * in0.x, in0.y * in0.y, in0.z * in0.z), mixRate);   // SH:661
+    aa = pt_make3(pt_sqrt(aa.x), pt_sqrt(aa.y), pt_sqrt(aa.z));
+    f3 in1 = cur(fx + offx, fy + 0.0f), in2 = cur(fx + -offx, fy + 0.0f);                    // SH:673-680
+    f3 in3 = cur(fx + 0.0f, fy + offy), in4 = cur(fx + 0.0f, fy + -offy);
+    f3 in5 = cur(fx + offx, fy + offy), in6 = cur(fx + -offx, fy + offy);
+    f3 in7 = cur(fx + offx, fy + -offy), in8 = cur(fx + -offx, fy + -offy);
+    aa = encode_pal_yuv(aa);
+    in0 = encode_pal_yuv(in0); in1 = encode_pal_yuv(in1); in2 = encode_pal_yuv(in2); in3 = encode_pal_yuv(in3); in4 = encode_pal_yuv(in4);
+    in5 = encode_pal_yuv(in5); in6 = encode_pal_yuv(in6); in7 = encode_pal_yuv(in7); in8 = encode_pal_yuv(in8);
+    f3 minColor = vmin3(vmin3(vmin3(in0, in1), vmin3(in2, in3)), in4);                       // SH:693-698
+    f3 maxColor = vmax3(vmax3(vmax3(in0, in1), vmax3(in2, in3)), in4);
+    minColor = vlerp3(minColor, vmin3(vmin3(vmin3(in5, in6), vmin3(in7, in8)), minColor), 0.5f);
+    maxColor = vlerp3(maxColor, vmax3(vmax3(vmax3(in5, in6), vmax3(in7, in8)), maxColor), 0.5f);
+    const f3 preclamping = aa;
+    aa = vmin3(vmax3(aa, minColor), maxColor);                                               // clamp(), SH:701
+    mixRate = 1.0f / (1.0f / mixRate + 1.0f);                                                // SH:703
+    const f3 diff = pt_sub3(aa, preclamping);
+    mixRate += pt_dot3(diff, diff) * 4.0f;                                                   // SH:706-708
+    mixRate = pt_min(pt_max(mixRate, 0.05f), 0.5f);
+    aa = decode_pal_yuv(aa);
+    a.result[(size_t)y * a.W + x] = make_float4(aa.x, aa.y, aa.z, mixRate);                  // SH:713, SH:929
+}
+
+}  // namespace ptrace

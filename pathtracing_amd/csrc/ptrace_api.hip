@@ -16,6 +16,7 @@
 #include "bvh.hpp"
 #include "pt_device.hpp"
 #include "pt_wavefront.hpp"
+#include "pt_screen.hpp"
 
 using namespace ptrace;
 
@@ -42,7 +43,11 @@ struct pt_context {
 
     // targets
     int W = 0, H = 0;
-    float4 *own_result = nullptr, *own_conv = nullptr;
+    float4 *own_result = nullptr, *own_conv = nullptr, *own_result2 = nullptr;
+    float4 *result2 = nullptr;                     // "Result2" (denoisedTex): renderMode 0's accumulated radiance
+    float4 *d_filtered = nullptr;                  // renderMode 0 scratch: the denoised image, and
+    float *d_seeds = nullptr;                      //   every pixel's running _Seed
+    size_t screen_pixels = 0;
     int32_t *own_ids = nullptr;
     float4 *result = nullptr, *conv = nullptr;
     int32_t *ids = nullptr;
@@ -413,7 +418,8 @@ void pt_destroy(pt_context *ctx)
     DeviceGuard g(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
-    free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
+    free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
+    free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
     free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -493,9 +499,13 @@ int pt_resize(pt_context *ctx, int width, int height)
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool rebind_r = ctx->result == ctx->own_result, rebind_c = ctx->conv == ctx->own_conv,
-               rebind_i = ctx->ids == ctx->own_ids;
-    free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids);
+               rebind_i = ctx->ids == ctx->own_ids, rebind_2 = ctx->result2 == ctx->own_result2;
+    free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
+    free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
+    ctx->screen_pixels = 0;
     size_t n = (size_t)width * height;
+    PT_HIP(ctx, hipMalloc((void **)&ctx->own_result2, n * sizeof(float4)));
+    PT_HIP(ctx, hipMemset(ctx->own_result2, 0, n * sizeof(float4)));
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_result, n * sizeof(float4)));
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_conv, n * sizeof(float4)));
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_ids, n * sizeof(int32_t)));
@@ -506,6 +516,7 @@ int pt_resize(pt_context *ctx, int width, int height)
     if (rebind_r || !ctx->result) ctx->result = ctx->own_result;
     if (rebind_c || !ctx->conv) ctx->conv = ctx->own_conv;
     if (rebind_i || !ctx->ids) ctx->ids = ctx->own_ids;
+    if (rebind_2 || !ctx->result2) ctx->result2 = ctx->own_result2;
     return PT_OK;
 }
 
@@ -519,6 +530,7 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
     case PT_TARGET_RESULT: ctx->result = device_ptr ? (float4 *)device_ptr : ctx->own_result; break;
     case PT_TARGET_CONVERGED: ctx->conv = device_ptr ? (float4 *)device_ptr : ctx->own_conv; break;
     case PT_TARGET_HIT_IDS: ctx->ids = device_ptr ? (int32_t *)device_ptr : ctx->own_ids; break;
+    case PT_TARGET_DENOISED: ctx->result2 = device_ptr ? (float4 *)device_ptr : ctx->own_result2; break;
     default: return fail(ctx, PT_ERR_INVALID, "pt_bind_target: unknown target");
     }
     return PT_OK;
@@ -529,23 +541,42 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     if (!ctx) return PT_ERR_INVALID;
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_render: params is NULL");
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_render before pt_resize");
-    if (p->render_mode != 1 && p->render_mode != 2)
-        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 1 (Default) and 2 (Reproj) are implemented");
-    if (p->render_mode == 2 && p->accumulate != PT_ACCUM_NONE)
-        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 2 uses the converged target as its history; accumulate must be PT_ACCUM_NONE");
+    if (p->render_mode != 0 && p->render_mode != 1 && p->render_mode != 2)
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 0 (Denoise), 1 (Default) and 2 (Reproj) are implemented");
+    if (p->render_mode != 1 && p->accumulate != PT_ACCUM_NONE)
+        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 0 and 2 use the converged target as their history; accumulate must be PT_ACCUM_NONE");
     if (p->max_bounces < 1) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be >= 1");
     if (p->accumulate < PT_ACCUM_NONE || p->accumulate > PT_ACCUM_ADDMAT) return fail(ctx, PT_ERR_INVALID, "pt_render: bad accumulate mode");
     int x0 = 0, y0 = 0, tw = ctx->W, th = ctx->H;
     if (p->tile_w > 0 && p->tile_h > 0) { x0 = p->tile_x0; y0 = p->tile_y0; tw = p->tile_w; th = p->tile_h; }
     if (x0 < 0 || y0 < 0 || (int64_t)x0 + tw > ctx->W || (int64_t)y0 + th > ctx->H)
         return fail(ctx, PT_ERR_INVALID, "pt_render: tile outside the image");
+    if (p->render_mode == 0 && (tw != ctx->W || th != ctx->H))
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode 0 filters across pixels and renders whole frames only");
     DeviceGuard g(ctx->device);
     int rc;
     if (ctx->scene_dirty) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if ((rc = rebuild_scene(ctx))) return rc;
     }
+    if (p->render_mode != 1) {
+        // SH:728-736, Result1 = Result (renderMode 2) or Result2 (renderMode 0) over the dispatched rectangle,
+        // finished before any pixel is traced
+        const float4 *src = p->render_mode == 0 ? ctx->result2 : ctx->result;
+        const size_t pitch = (size_t)ctx->W * sizeof(float4);
+        PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)y0 * ctx->W + x0, pitch, src + (size_t)y0 * ctx->W + x0, pitch,
+                                     (size_t)tw * sizeof(float4), (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (p->depth != 1 && p->samples_per_pixel <= 0) return PT_OK;  // the shader's sample loop does not run
+    const bool screen_passes = p->render_mode == 0 && p->depth != 1;
+    if (screen_passes && ctx->screen_pixels < (size_t)ctx->W * ctx->H) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
+        ctx->screen_pixels = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_filtered, (size_t)ctx->W * ctx->H * sizeof(float4)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_seeds, (size_t)ctx->W * ctx->H * sizeof(float)));
+        ctx->screen_pixels = (size_t)ctx->W * ctx->H;
+    }
 
     RenderArgs a;
     a.sc = scene_dev(ctx);
@@ -572,12 +603,7 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         std::memcpy(a.old_w2c, h0.world_to_camera, sizeof a.old_w2c);
         std::memcpy(a.old_proj, h0.camera_projection, sizeof a.old_proj);
     }
-    if (p->render_mode == 2 && p->depth != 1) {
-        // SH:728-731, Result1 = Result over the dispatched rectangle, finished before any pixel is traced
-        const size_t pitch = (size_t)ctx->W * sizeof(float4);
-        PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)y0 * ctx->W + x0, pitch, ctx->result + (size_t)y0 * ctx->W + x0, pitch,
-                                     (size_t)tw * sizeof(float4), (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    a.result2 = ctx->result2; a.seed_out = ctx->d_seeds;
 
     if (!ctx->epoch_open) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, kStatsShards * kStatsStride * sizeof(unsigned long long), ctx->stream));
@@ -596,6 +622,16 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
         if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PT_HIP(ctx, hipGetLastError());
+    }
+    if (screen_passes) {
+        // SH:928-929 as two launches: filter every pixel, then resolve every pixel
+        ScreenArgs sa;
+        sa.history = ctx->conv; sa.seeds = ctx->d_seeds; sa.filtered = ctx->d_filtered; sa.result = ctx->result;
+        sa.W = ctx->W; sa.H = ctx->H;
+        const dim3 blk(kScreenBlockX, kScreenBlockY), grd((ctx->W + kScreenBlockX - 1) / kScreenBlockX, (ctx->H + kScreenBlockY - 1) / kScreenBlockY);
+        hipLaunchKernelGGL(denoise_kernel, grd, blk, 0, ctx->stream, sa);
+        hipLaunchKernelGGL(taa_kernel, grd, blk, 0, ctx->stream, sa, a);
         PT_HIP(ctx, hipGetLastError());
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -671,6 +707,33 @@ int pt_write_converged(pt_context *ctx, const float *in)
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(ctx->conv, in, (size_t)ctx->W * ctx->H * 16, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+static float4 *target_of(pt_context *ctx, int which)
+{
+    switch (which) {
+    case PT_TARGET_RESULT: return ctx->result;
+    case PT_TARGET_CONVERGED: return ctx->conv;
+    case PT_TARGET_DENOISED: return ctx->result2;
+    default: return nullptr;
+    }
+}
+int pt_read_target(pt_context *ctx, int which, float *out)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    float4 *src = target_of(ctx, which);
+    if (!src && ctx->W) return fail(ctx, PT_ERR_INVALID, "pt_read_target: not an RGBA target");
+    return read_back(ctx, out, src, (size_t)ctx->W * ctx->H * 16);
+}
+int pt_write_target(pt_context *ctx, int which, const float *in)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    float4 *dst = target_of(ctx, which);
+    if (!in || ctx->W == 0 || !dst) return fail(ctx, PT_ERR_INVALID, "pt_write_target: bad arguments");
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(dst, in, (size_t)ctx->W * ctx->H * 16, hipMemcpyHostToDevice));
     return PT_OK;
 }
 

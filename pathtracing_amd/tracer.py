@@ -117,6 +117,16 @@ class PathTracer:
         assert a.shape == (self.height, self.width, 4)
         self._check(self._lib.pt_write_converged(self._ctx, a.ctypes.data), "pt_write_converged")
 
+    def read_target(self, which):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.pt_read_target(self._ctx, int(which), out.ctypes.data), "pt_read_target")
+        return out
+
+    def write_target(self, which, img):
+        a = np.ascontiguousarray(img, np.float32)
+        assert a.shape == (self.height, self.width, 4)
+        self._check(self._lib.pt_write_target(self._ctx, int(which), a.ctypes.data), "pt_write_target")
+
     def read_hit_ids(self):
         out = np.empty((self.height, self.width), np.int32)
         self._check(self._lib.pt_read_hit_ids(self._ctx, out.ctypes.data), "pt_read_hit_ids")

@@ -11,28 +11,32 @@ def camera_at(scene, k, step=(0.12, 0.05, 0.2)):
     return eye, tuple(float(v) for v in scene.target)
 
 
-def frame_params(scene, W, H, k, spp, max_bounces, frames_n, step=(0.12, 0.05, 0.2), tile=None, depth=0):
+def frame_params(scene, W, H, k, spp, max_bounces, frames_n, step=(0.12, 0.05, 0.2), tile=None, depth=0, mode=2):
     eye, target = camera_at(scene, k, step)
     p = pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=spp, max_bounces=max_bounces, eye=eye, target=target,
-                       render_mode=2, accumulation_frames=frames_n, tile=tile, depth=depth)
+                       render_mode=mode, accumulation_frames=frames_n, tile=tile, depth=depth)
     h = pa.camera_history_entry(eye, target, scene.fov, W / H)
     return p, h
 
 
 def oracle_sequence(oracle, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5, threads=4, **kw):
+    """Per frame: (Result, Result1, hit ids, stats[, Result2 in renderMode 0])."""
     result = np.zeros((H, W, 4), np.float32); result1 = np.zeros((H, W, 4), np.float32)
+    result2 = np.zeros((H, W, 4), np.float32) if kw.get("mode", 2) == 0 else None
     hist = []
     out = []
     for k in range(n_frames):
         p, h = frame_params(scene, W, H, k, spp, max_bounces, frames_n, **kw)
-        ids, st = oracle.render_history(p, hist, W, H, result, result1, threads=threads)
+        ids, st = oracle.render_history(p, hist, W, H, result, result1, threads=threads, result2=result2)
         hist = [h]
-        out.append((result.copy(), result1.copy(), ids, st))
+        out.append((result.copy(), result1.copy(), ids, st) + ((result2.copy(),) if result2 is not None else ()))
     return out
 
 
 def gpu_sequence(tracer, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5, **kw):
-    tracer.write_converged(np.zeros((H, W, 4), np.float32))
+    for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED, pa.PT_TARGET_DENOISED):
+        tracer.write_target(which, np.zeros((H, W, 4), np.float32))
+    mode0 = kw.get("mode", 2) == 0
     hist = []
     out = []
     for k in range(n_frames):
@@ -41,5 +45,6 @@ def gpu_sequence(tracer, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5
         tracer.stats()
         tracer.render(p)
         hist = [h]
-        out.append((tracer.read_result(), tracer.read_converged(), tracer.read_hit_ids(), tracer.stats()))
+        out.append((tracer.read_result(), tracer.read_converged(), tracer.read_hit_ids(), tracer.stats())
+                   + ((tracer.read_target(pa.PT_TARGET_DENOISED),) if mode0 else ()))
     return out

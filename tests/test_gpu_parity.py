@@ -388,7 +388,7 @@ def test_reprojection_without_history_and_errors(tracer):
     with pytest.raises(pa.PtraceError, match="accumulate"):
         tracer.render(bad)
     with pytest.raises(pa.PtraceError, match="renderMode"):
-        tracer.render(pa.make_params(s, W, H, render_mode=0))
+        tracer.render(pa.make_params(s, W, H, render_mode=3))
     # depth dispatch in renderMode 2: SH:799-809 returns before any reprojection
     d2 = pa.make_params(s, W, H, depth=1, render_mode=2)
     d1 = pa.make_params(s, W, H, depth=1)
@@ -434,3 +434,55 @@ def test_master_mirror_reproj_mode_keeps_the_camera_history():
         assert taken > 500
     finally:
         lib.ptm_master_destroy(h)
+
+
+# ------------------------------------------- renderMode 0 (reprojection + denoiser + TAA)
+
+def test_denoise_mode_sequence_matches_oracle_bit_exact(tracer):
+    """Three frames with a moving camera in the reference's start-up mode: Result (what the app displays), Result1
+    (history) and Result2 (accumulated radiance) of every frame equal the oracle's, bit for bit."""
+    from reproj_util import gpu_sequence, oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    W, H = 64, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_sequence(o, s, W, H, 3, spp=2, max_bounces=4, frames_n=5, mode=0)
+    got = gpu_sequence(tracer, s, W, H, 3, spp=2, max_bounces=4, frames_n=5, mode=0)
+    for k in range(3):
+        for name, i in (("Result2", 4), ("Result1", 1), ("Result", 0)):
+            assert (got[k][i].view(np.uint32) == want[k][i].view(np.uint32)).all(), f"{name}, frame {k}"
+        assert got[k][3]["rays"] == want[k][3]["rays"]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "denoise_64x36.npz"))
+    assert (got[2][0].view(np.uint32) == g["result2"].view(np.uint32)).all()
+    assert (got[2][4].view(np.uint32) == g["result2_2"].view(np.uint32)).all()
+
+
+def test_denoise_mode_mesh_scene_odd_size(tracer):
+    from reproj_util import gpu_sequence, oracle_sequence
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(256, 128)
+    W, H = 131, 77                                        # neither a multiple of the 64x4 launch tile nor of 32 rows
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_sequence(o, s, W, H, 3, spp=1, max_bounces=8, frames_n=10, threads=8, mode=0)
+    got = gpu_sequence(tracer, s, W, H, 3, spp=1, max_bounces=8, frames_n=10, mode=0)
+    for k in range(3):
+        for name, i in (("Result2", 4), ("Result1", 1), ("Result", 0)):
+            assert (got[k][i].view(np.uint32) == want[k][i].view(np.uint32)).all(), f"{name}, frame {k}"
+    assert got[2][0][..., :3].mean() > 0.02
+
+
+def test_denoise_mode_errors_and_depth(tracer):
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    W, H = 40, 24
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    with pytest.raises(pa.PtraceError, match="whole frames"):
+        tracer.render(pa.make_params(s, W, H, render_mode=0, tile=(0, 0, 20, 10)))
+    with pytest.raises(pa.PtraceError, match="accumulate"):
+        tracer.render(pa.make_params(s, W, H, render_mode=0, accumulate=pa.PT_ACCUM_SUM))
+    tracer.render(pa.make_params(s, W, H, depth=1)); want = tracer.read_result()
+    marker = np.full((H, W, 4), 0.125, np.float32)
+    tracer.write_target(pa.PT_TARGET_DENOISED, marker)
+    tracer.render(pa.make_params(s, W, H, depth=1, render_mode=0))
+    assert (tracer.read_result().view(np.uint32) == want.view(np.uint32)).all()   # SH:799-809 returns before the mode-0 block
+    assert (tracer.read_converged() == marker).all()                              # but after Result1 = Result2 (SH:733-736)
+    assert (tracer.read_target(pa.PT_TARGET_DENOISED) == marker).all()

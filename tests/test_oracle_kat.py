@@ -412,3 +412,82 @@ def test_reprojection_golden_sequence():
     for k, (res, hist, ids, st) in enumerate(seq):
         assert (res.view(np.uint32) == g[f"result{k}"].view(np.uint32)).all(), k
     assert int(g["taken2"]) == int((np.abs(seq[2][0][..., 3] - g["plain_alpha2"]) > 0).sum())
+
+
+# ------------------------------------------- renderMode 0 (denoiser + TAA)
+
+def test_denoiser_kat():
+    """denoiser() (SH:479-615): on a constant image every tap has weight 1, so an interior pixel keeps its
+    value; taps outside the image read zero and pull border pixels down; the output is clamped to [0,1] with
+    alpha 0; the tap stride is 1 + 3*hash1(641.128752 x + 312.321374 y + 1.92357812 _Seed)."""
+    W, H = 40, 30
+    img = np.zeros((H, W, 4), np.float32); img[..., :3] = (0.25, 0.5, 0.75); img[..., 3] = 7.0
+    out = po.denoiser(img, 20, 15, 3.5)
+    assert np.allclose(out, [0.25, 0.5, 0.75, 0.0], atol=1e-6)
+    edge = po.denoiser(img, 0, 0, 3.5)
+    assert (edge[:3] < np.array([0.25, 0.5, 0.75])).all() and (edge[:3] > 0).all()
+    img[..., :3] = 2.0
+    assert (po.denoiser(img, 20, 15, 3.5) == np.array([1, 1, 1, 0], np.float32)).all()       # clamp (SH:614)
+    # a single bright texel next to a dark pixel is suppressed by the colour weight exp(-|dc|^2)
+    img[..., :3] = 0.0; img[15, 21, :3] = 3.0
+    strength = 1.0 + 3.0 * po.fmath("frac", po.fmath("sin", np.float32(641.128752) * np.float32(20) + np.float32(312.321374) * np.float32(15)
+                                                     + np.float32(1.92357812) * np.float32(3.5)) * np.float32(43758.5453123))
+    got = po.denoiser(img, 20, 15, 3.5)
+    if strength < 2.0:      # tap (1, 0) * strength lands on texel 21 only while strength < 2
+        w = np.exp(-27.0) * (1 / 4 * 3 / 8)
+        assert np.allclose(got[:3], 3.0 * w / (1.0 - 3 / 32 + w), rtol=1e-3, atol=1e-12)
+    else:
+        assert (got[:3] == 0).all()
+
+
+def test_taa_kat():
+    """TAA() (SH:644-714) on constant images: history h, current c -> the clamp to the neighbourhood's range
+    returns c, and the mix rate is clamp(1/3 + 4 |yuv(c) - yuv(sqrt((h^2+c^2)/2))|^2, 0.05, 0.5)."""
+    W, H = 24, 16
+    hist = np.zeros((H, W, 4), np.float32); cur = np.zeros((H, W, 4), np.float32)
+    hist[..., :3] = 0.4; cur[..., :3] = 0.4
+    out = po.taa(hist, cur, 10, 8)
+    assert np.allclose(out[:3], 0.4, atol=2e-6) and np.isclose(out[3], 1.0 / 3.0, rtol=1e-6)
+    cur[..., :3] = (0.1, 0.5, 0.9)
+    out = po.taa(hist, cur, 10, 8)
+    assert np.allclose(out[:3], (0.1, 0.5, 0.9), atol=1e-4)      # the two YUV matrices are 5-digit inverses of each other
+    assert 1.0 / 3.0 < out[3] <= 0.5
+    # the "+off" neighbours are the pixel itself, the "-off" ones its left / upper neighbours (index truncation):
+    # a bright texel to the right or below does not widen the clamp range, one to the left does
+    hist[..., :3] = 0.9; cur[..., :3] = 0.2
+    base = po.taa(hist, cur, 10, 8)
+    cur2 = cur.copy(); cur2[8, 11, :3] = 1.0; cur2[9, 10, :3] = 1.0
+    assert (po.taa(hist, cur2, 10, 8) == base).all()
+    cur3 = cur.copy(); cur3[8, 9, :3] = 1.0
+    assert (po.taa(hist, cur3, 10, 8)[:3] > base[:3]).all()
+
+
+def test_denoise_mode_sequence_properties_and_golden():
+    from reproj_util import oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    o = po.Oracle.from_scene(s, sky)
+    W, H = 64, 36
+    seq = oracle_sequence(o, s, W, H, 3, spp=2, max_bounces=4, frames_n=5, mode=0)
+    ref2 = oracle_sequence(o, s, W, H, 3, spp=2, max_bounces=4, frames_n=5, mode=2)
+    r0, h0, _, _, acc0 = seq[0]
+    assert (h0 == 0).all()                                      # Result1 = Result2 of the (empty) previous frame, SH:735
+    assert (acc0 == ref2[0][0]).all()                           # no history: Result2 = the fresh frame, as renderMode 2 writes Result
+    assert (r0[..., :3] == 0).all() and np.allclose(r0[..., 3], 1.0 / 3.0)   # denoiser + TAA of an all-zero history
+    r1, h1, _, _, acc1 = seq[1]
+    assert (h1 == acc0).all()
+    assert r1[..., :3].max() < 1.5 and r1[..., :3].min() >= 0.0 and r1[..., :3].mean() > 0.05   # the YUV round trip is not clamped
+    # Result2 follows renderMode 2's rule except below a thread group's last row (SH:908-915)
+    same = (acc1 == ref2[1][0]).all(-1)
+    assert 0.9 < same.mean() <= 1.0
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "denoise_64x36.npz"))
+    for k in range(3):
+        assert (seq[k][0].view(np.uint32) == g[f"result{k}"].view(np.uint32)).all(), k
+        assert (seq[k][4].view(np.uint32) == g[f"result2_{k}"].view(np.uint32)).all(), k
+
+
+def test_exp_accuracy():
+    xs = np.concatenate([np.linspace(-80, 5, 4001), [-0.0, 0.0, -1e-8]]).astype(np.float32)
+    got = np.array([po.fmath("exp", float(x)) for x in xs], np.float64)
+    want = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(got - want) / want) < 2e-5      # |x| * 2^-24 from rounding x*log2(e), plus the exp2 kernel
+    assert po.fmath("exp", -0.0) == 1.0

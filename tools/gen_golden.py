@@ -56,3 +56,11 @@ rp["plain_alpha2"] = plain2[..., 3]
 rp["taken2"] = np.int64((np.abs(seq[2][0][..., 3] - plain2[..., 3]) > 0).sum())
 np.savez_compressed(os.path.join(out, "reproj_64x36.npz"), **rp)
 print("wrote reproj_64x36.npz; pixels that took the history in frame 2:", int(rp["taken2"]), "of", W * H)
+
+# (ix) renderMode 0: the same three frames through reprojection -> Result2, denoiser and TAA -> Result
+seq0 = oracle_sequence(o, s, W, H, 3, spp=2, max_bounces=4, frames_n=5, mode=0)
+dn = {}
+for k, fr in enumerate(seq0):
+    dn[f"result{k}"] = fr[0]; dn[f"result2_{k}"] = fr[4]
+np.savez_compressed(os.path.join(out, "denoise_64x36.npz"), **dn)
+print("wrote denoise_64x36.npz; mean of the displayed frame 2:", float(seq0[2][0][..., :3].mean()))
