@@ -190,6 +190,8 @@ def main():
         }
         if not args.no_stereo and world == 1:
             out["stereo_1080p"] = stereo_frame_time(pa, torch)
+        if not args.no_stereo and world == 1:
+            out["blob70k_1080p"] = secondary_scene_rate(pa, torch, sky)
         if not args.no_reproj and world == 1:
             out["reproj_1080p"] = reproj_frame_time(pa, torch, scene, sky)
         if world == 1 and not args.no_cpu_baseline:
@@ -232,6 +234,23 @@ def stereo_frame_time(pa, torch, frames=30):
     for t in eyes:
         t.close()
     return {"ms_per_frame": ms, "frames": frames, "config": "xr scene, 2 x 1920x1080, 1 spp, 4 bounces, mean accumulation, 1 GPU"}
+
+
+def secondary_scene_rate(pa, torch, sky, frames=5):
+    """Mrays/s on the ~70 k-triangle mesh scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU)."""
+    scene = pa.Scene("blob70k")
+    t = pa.PathTracer(torch.cuda.current_device())
+    t.load_scene(scene, sky); t.resize(1920, 1080)
+    t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(0), spp=16, max_bounces=8)); t.stats()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(1 + k), spp=16, max_bounces=8))
+    t.sync()
+    dt = time.perf_counter() - t0
+    st = t.stats()
+    t.close()
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
+            "config": f"blob70k ({scene.n_triangles} triangles + spheres + plane), 1920x1080, 8 bounces, 16 spp, 1 GPU"}
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):

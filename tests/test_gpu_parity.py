@@ -327,6 +327,40 @@ def test_ten_million_triangles(tracer):
     assert np.isfinite(img).all() and np.allclose(dep[hit][:, 0] * 16.0, img[hit][:, 3], rtol=2e-6) and np.isinf(dep[~hit]).all()
 
 
+def test_xr_stereo_frame_full_size():
+    """The stereo XR case at its full size: two eyes of 2064x2208, 4 bounces, 1 spp + running-mean accumulation,
+    one context per eye (both on this GPU; on two GPUs each rank owns one).  A tile of each eye is compared with
+    the oracle bit for bit over two accumulated frames; whole-frame properties cover the rest."""
+    s = pa.Scene("xr"); sky = pa.procedural_sky(512, 256)
+    W, H = 2064, 2208
+    sep = 0.022                                                # TestScene.unity:870
+    tile = (W // 2 - 64, H // 2 - 40, 128, 80)
+    ys, xs = slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2])
+    orc = po.Oracle.from_scene(s, sky, accel=True)
+    images = []
+    for e in range(2):
+        off = np.array([(-0.5 + e) * sep, 0, 0], np.float32)
+        eye, target = s.eye + off, s.target + off
+        with pa.PathTracer(0) as tr:
+            tr.load_scene(s, sky); tr.resize(W, H)
+            conv = np.zeros((tile[3], tile[2], 4), np.float32)
+            for k in range(2):
+                kw = dict(seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=eye, target=target, fov=90.0)
+                tr.stats()
+                tr.render(pa.make_params(s, W, H, accumulate=pa.PT_ACCUM_MEAN, sample_index=k, **kw))
+                st = tr.stats()
+                assert st["paths"] == W * H and W * H < st["rays"] <= 4 * W * H
+                fresh, _, _ = orc.render(pa.make_params(s, W, H, tile=tile, **kw), W, H, threads=8)
+                conv = po.accumulate(pa.PT_ACCUM_MEAN, k, fresh[ys, xs], conv)
+                _assert_same_image(tr.read_result()[ys, xs], fresh[ys, xs], f"eye {e} frame {k}")
+            full = tr.read_converged()
+            _assert_same_image(full[ys, xs], conv, f"eye {e} converged")
+            assert np.isfinite(full).all() and (full[..., :3] >= 0).all()
+            images.append(full)
+    assert not (images[0] == images[1]).all()                  # the eyes see different images ...
+    assert abs(float(images[0][..., :3].mean()) - float(images[1][..., :3].mean())) < 0.02   # ... of the same scene
+
+
 # ---------------------------------------------------- renderMode 2 (reprojection)
 
 def test_reprojection_sequence_matches_oracle_bit_exact(tracer):
