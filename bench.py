@@ -188,6 +188,14 @@ def main():
             "image_crc": int(np.bitwise_xor.reduce(np.ascontiguousarray(img).view(np.uint32).reshape(-1))),
             "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
         }
+        # what a transform change costs: matrices in, primitive records and node boxes redone on the device
+        tr.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.update_transforms(scene.objects)
+        tr.sync()
+        out["bvh"]["refit_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        out["bvh"]["objects"] = int(len(scene.objects))
         if not args.no_stereo and world == 1:
             out["stereo_1080p"] = stereo_frame_time(pa, torch)
         if not args.no_stereo and world == 1:

@@ -140,6 +140,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *   "backend"    0 (default): one persistent kernel whose waves vote between node, leaf and shade phases;
  *                1: wavefront stages - generate / persistent trace / shade+compact+regenerate (renderMode 1 only).
  *   "bvh_width"  4 (default): four-child nodes with 8-bit boxes; 2: two-child nodes with float boxes.
+ *   "refit"      1 (default): pt_update_transforms refits the four-wide tree on the device; 0: it rebuilds on the host.
  * All combinations produce the same image bit for bit. */
 int pt_set_option(pt_context *ctx, const char *name, int value);
 
@@ -157,7 +158,11 @@ int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects,
                   const int32_t *indices, int n_indices);
 
 /* Same geometry, new localToWorld matrices (what a transform change costs the
- * reference: a full re-upload, RayTracingMaster.cs:254-262,371-413). */
+ * reference: a full re-upload, RayTracingMaster.cs:254-262,371-413).  On a scene
+ * that has been rendered this sends only the matrices and refits the
+ * acceleration structure on the device, ordered on the context's stream; the
+ * tree keeps the topology of the last full build (pt_set_meshes, or option
+ * "refit" 0), so large motion costs traversal speed, never correctness. */
 int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_objects);
 
 /* _SkyboxTexture (RayTracingMaster.cs:457): RGBA float32, w*h texels, row 0 at

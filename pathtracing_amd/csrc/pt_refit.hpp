@@ -1,0 +1,138 @@
+// Refit of the four-wide BVH on the device after a change of localToWorld matrices.
+//
+// The reference re-uploads every vertex, index and matrix whenever a watched transform changes
+// (RayTracingMaster.cs:254-262, 371-413) and its shader transforms every triangle per ray
+// (RayTracingShader.compute:238-240).  Here the object-space geometry stays on the device: an
+// update sends the matrices (64 bytes per object), refit_prims_kernel redoes the world-space
+// primitive records and their boxes, and refit_nodes_kernel recomputes the node boxes level by
+// level from the leaves up.  The tree's topology is the one of the last full build, so its quality
+// decays with large motion (a full build restores it); its answers do not: every box still
+// contains its primitives, and the closest hit does not depend on the tree.
+#pragma once
+
+#include "bvh.hpp"
+#include "pt_device.hpp"
+
+namespace ptrace {
+
+struct RefitArgs {
+    const int4 *slot_src;     // per primitive slot: (object index or -1 for a sphere, vertex index 0, 1, 2)
+    const float *vertices;    // object-space positions, 3 floats per vertex
+    const float *matrices;    // 16 floats per object (UnityEngine.Matrix4x4 memory order)
+    float4 *prims;            // the primitive records (pt_device.hpp)
+    float *prim_box;          // 6 floats per slot: padded world-space box, lo then hi
+    uint4 *nodes4;            // Bvh4Node array
+    float *node_box;          // 6 floats per node: exact union of its children's boxes
+    const int32_t *level_nodes;   // node indices, deepest level first
+    float pad;                // absolute padding of primitive boxes (from the last full build)
+    int32_t n_prims;
+};
+
+constexpr int kRefitBlock = 256;
+
+__global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArgs a)
+{
+    const int slot = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (slot >= a.n_prims) return;
+    const int4 src = a.slot_src[slot];
+    float lo[3], hi[3];
+    if (src.x >= 0) {
+        const float *m = a.matrices + 16 * (size_t)src.x;
+        float mm[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) mm[k] = m[k];
+        const float *pa = a.vertices + 3 * (size_t)src.y, *pb = a.vertices + 3 * (size_t)src.z, *pc = a.vertices + 3 * (size_t)src.w;
+        // RayTracingShader.compute:238-240
+        const f3 v0 = pt_mul_point(mm, pt_make3(pa[0], pa[1], pa[2]));
+        const f3 v1 = pt_mul_point(mm, pt_make3(pb[0], pb[1], pb[2]));
+        const f3 v2 = pt_mul_point(mm, pt_make3(pc[0], pc[1], pc[2]));
+        const f3 e1 = pt_sub3(v1, v0), e2 = pt_sub3(v2, v0);
+        const float idf = a.prims[(size_t)slot * 3].w;
+        a.prims[(size_t)slot * 3 + 0] = make_float4(v0.x, v0.y, v0.z, idf);
+        a.prims[(size_t)slot * 3 + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+        a.prims[(size_t)slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        lo[0] = fminf(v0.x, fminf(v1.x, v2.x)); hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+        lo[1] = fminf(v0.y, fminf(v1.y, v2.y)); hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+        lo[2] = fminf(v0.z, fminf(v1.z, v2.z)); hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+        // a NaN coordinate must widen the box, not vanish in fmin/fmax
+        if (!(v0.x == v0.x && v1.x == v1.x && v2.x == v2.x)) { lo[0] = -PT_INF; hi[0] = PT_INF; }
+        if (!(v0.y == v0.y && v1.y == v1.y && v2.y == v2.y)) { lo[1] = -PT_INF; hi[1] = PT_INF; }
+        if (!(v0.z == v0.z && v1.z == v1.z && v2.z == v2.z)) { lo[2] = -PT_INF; hi[2] = PT_INF; }
+    } else {
+        const float4 c = a.prims[(size_t)slot * 3 + 0];
+        const float r = fabsf(a.prims[(size_t)slot * 3 + 1].x);
+        lo[0] = c.x - r; hi[0] = c.x + r; lo[1] = c.y - r; hi[1] = c.y + r; lo[2] = c.z - r; hi[2] = c.z + r;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float l = lo[k], h = hi[k];
+        const bool finite = fabsf(l) < PT_INF && fabsf(h) < PT_INF;
+        const float rel = 4e-7f * fmaxf(fabsf(l), fabsf(h));
+        a.prim_box[(size_t)slot * 6 + k] = finite ? l - a.pad - rel : -PT_INF;
+        a.prim_box[(size_t)slot * 6 + 3 + k] = finite ? h + a.pad + rel : PT_INF;
+    }
+}
+
+// One thread per node of one tree level (children first, so every child's box is ready).
+__global__ __launch_bounds__(kRefitBlock) void refit_nodes_kernel(const RefitArgs a, int first, int count)
+{
+    const int t = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (t >= count) return;
+    const int node = a.level_nodes[first + t];
+    Bvh4Node nd = *reinterpret_cast<const Bvh4Node *>(a.nodes4 + (size_t)node * 4);
+    float clo[4][3], chi[4][3];
+    float plo[3] = {PT_INF, PT_INF, PT_INF}, phi[3] = {-PT_INF, -PT_INF, -PT_INF};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!((nd.valid >> k) & 1)) continue;
+        const int32_t link = nd.child[k];
+        if (link < 0) {
+            const uint32_t enc = (uint32_t)~link, firstp = enc >> 3, cnt = (enc & 7u) + 1u;
+            for (int ax = 0; ax < 3; ax++) { clo[k][ax] = PT_INF; chi[k][ax] = -PT_INF; }
+            for (uint32_t q = 0; q < cnt; q++)
+                for (int ax = 0; ax < 3; ax++) {
+                    clo[k][ax] = fminf(clo[k][ax], a.prim_box[(size_t)(firstp + q) * 6 + ax]);
+                    chi[k][ax] = fmaxf(chi[k][ax], a.prim_box[(size_t)(firstp + q) * 6 + 3 + ax]);
+                }
+        } else {
+            for (int ax = 0; ax < 3; ax++) { clo[k][ax] = a.node_box[(size_t)link * 6 + ax]; chi[k][ax] = a.node_box[(size_t)link * 6 + 3 + ax]; }
+        }
+        for (int ax = 0; ax < 3; ax++) { plo[ax] = fminf(plo[ax], clo[k][ax]); phi[ax] = fmaxf(phi[ax], chi[k][ax]); }
+    }
+    for (int ax = 0; ax < 3; ax++) { a.node_box[(size_t)node * 6 + ax] = plo[ax]; a.node_box[(size_t)node * 6 + 3 + ax] = phi[ax]; }
+    // the node's grid: origin = low corner, per axis the smallest power-of-two cell with 255 cells >= extent
+    float cell[3];
+    uint8_t ebits[3];
+    for (int ax = 0; ax < 3; ax++) {
+        nd.org[ax] = plo[ax];
+        const float ext = phi[ax] - plo[ax];
+        int e = -100;
+        if (ext > 0.0f && ext < PT_INF) {
+            (void)frexpf(ext / 255.0f, &e);
+            if (e < -100) e = -100;
+            while (plo[ax] + 255.0f * ldexpf(1.0f, e) < phi[ax] && e < 100) e++;
+        }
+        cell[ax] = ldexpf(1.0f, e);
+        ebits[ax] = (uint8_t)(e + 127);
+    }
+    nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!((nd.valid >> k) & 1)) {
+            for (int ax = 0; ax < 3; ax++) { nd.qlo[ax][k] = 255; nd.qhi[ax][k] = 0; }
+            continue;
+        }
+        for (int ax = 0; ax < 3; ax++) {
+            const float fl = floorf((clo[k][ax] - plo[ax]) / cell[ax]), fh = ceilf((chi[k][ax] - plo[ax]) / cell[ax]);
+            int ql = (int)fminf(255.0f, fmaxf(0.0f, fl)), qh = (int)fminf(255.0f, fmaxf(0.0f, fh));
+            if (!(fl == fl)) ql = 0;                       // an infinite or NaN extent: the whole grid
+            if (!(fh == fh)) qh = 255;
+            while (ql > 0 && plo[ax] + (float)ql * cell[ax] > clo[k][ax]) ql--;     // outward rounding survives
+            while (qh < 255 && plo[ax] + (float)qh * cell[ax] < chi[k][ax]) qh++;   // the float arithmetic
+            nd.qlo[ax][k] = (uint8_t)ql; nd.qhi[ax][k] = (uint8_t)qh;
+        }
+    }
+    *reinterpret_cast<Bvh4Node *>(a.nodes4 + (size_t)node * 4) = nd;
+}
+
+}  // namespace ptrace

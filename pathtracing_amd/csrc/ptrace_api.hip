@@ -17,6 +17,7 @@
 #include "pt_device.hpp"
 #include "pt_wavefront.hpp"
 #include "pt_screen.hpp"
+#include "pt_refit.hpp"
 
 using namespace ptrace;
 
@@ -33,6 +34,18 @@ struct pt_context {
     std::vector<int32_t> indices;
     bool scene_dirty = true;
     std::vector<PtCameraHistory> camera_history;   // pt_set_camera_history
+
+    // refit state (pt_refit.hpp): what pt_update_transforms needs to redo boxes without a host build
+    int refit = 1;                                 // option "refit"
+    bool refit_ready = false;                      // the buffers below describe the current tree
+    int4 *d_slot_src = nullptr;
+    float *d_vertices = nullptr, *d_matrices = nullptr, *d_prim_box = nullptr, *d_node_box = nullptr;
+    int32_t *d_level_nodes = nullptr;
+    std::vector<int> level_first;                  // level_first[l] .. level_first[l+1]: nodes of level l, deepest level first
+    float box_pad = 0.0f;
+    hipEvent_t ev_refit = nullptr;
+    bool refit_in_flight = false;
+    bool bvh2_stale = false;                       // a refit updated only the four-wide tree
 
     // device scene
     uint4 *d_nodes4 = nullptr;
@@ -217,6 +230,53 @@ int rebuild_scene(pt_context *ctx)
         smat[i * 4 + 3] = make_float4(s.emission[0], s.emission[1], s.emission[2], 0.0f);
     }
     int rc;
+    // ---- what a later refit needs: per slot its source triangle, the object-space vertices, the tree's levels
+    ctx->refit_ready = false;
+    if (ctx->refit && !bvh.nodes4.empty()) {
+        std::vector<int32_t> tri_obj(tris.size()), tri_i0(tris.size()), tri_i1(tris.size()), tri_i2(tris.size());
+        size_t j = 0;
+        for (size_t o = 0; o < ctx->objects.size(); o++) {
+            const PtMeshObject &mo = ctx->objects[o];
+            const int32_t end = mo.indices_offset + mo.indices_count;
+            for (int32_t i = mo.indices_offset; i + 2 < end; i += 3, j++) {
+                tri_obj[j] = (int32_t)o; tri_i0[j] = ctx->indices[i]; tri_i1[j] = ctx->indices[i + 1]; tri_i2[j] = ctx->indices[i + 2];
+            }
+        }
+        std::vector<int4> slot_src(nP);
+        for (size_t slot = 0; slot < nP; slot++) {
+            uint32_t prim = bvh.order[slot];
+            if ((int)prim < nS) slot_src[slot] = make_int4(-1, 0, 0, 0);
+            else { size_t t = prim - nS; slot_src[slot] = make_int4(tri_obj[t], tri_i0[t], tri_i1[t], tri_i2[t]); }
+        }
+        // nodes are stored parents first, so one forward pass gives every node its level
+        const size_t nN = bvh.nodes4.size();
+        std::vector<int> level(nN, 0);
+        int max_level = 0;
+        for (size_t n = 0; n < nN; n++)
+            for (int k = 0; k < 4; k++)
+                if (((bvh.nodes4[n].valid >> k) & 1) && bvh.nodes4[n].child[k] >= 0) {
+                    level[bvh.nodes4[n].child[k]] = level[n] + 1;
+                    max_level = std::max(max_level, level[n] + 1);
+                }
+        std::vector<int> count(max_level + 2, 0);
+        for (size_t n = 0; n < nN; n++) count[max_level - level[n] + 1]++;       // deepest level first
+        for (int l = 0; l <= max_level; l++) count[l + 1] += count[l];
+        ctx->level_first.assign(count.begin(), count.end());
+        std::vector<int32_t> level_nodes(nN);
+        std::vector<int> cursor(count.begin(), count.end() - 1);
+        for (size_t n = 0; n < nN; n++) level_nodes[cursor[max_level - level[n]]++] = (int32_t)n;
+        std::vector<float> mats(ctx->objects.size() * 16);
+        for (size_t o = 0; o < ctx->objects.size(); o++) std::memcpy(&mats[o * 16], ctx->objects[o].local_to_world, 64);
+        if ((rc = upload(ctx, ctx->d_slot_src, slot_src.data(), slot_src.size() * sizeof(int4)))) return rc;
+        if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_level_nodes, level_nodes.data(), level_nodes.size() * sizeof(int32_t)))) return rc;
+        free_dev(ctx->d_prim_box); free_dev(ctx->d_node_box);
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_prim_box, nP * 6 * sizeof(float)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_node_box, nN * 6 * sizeof(float)));
+        ctx->box_pad = pad;
+        ctx->refit_ready = !ctx->objects.empty();
+    }
     if ((rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;
     if ((rc = upload(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
     ctx->n_nodes4 = (int)bvh.nodes4.size();
@@ -232,6 +292,7 @@ int rebuild_scene(pt_context *ctx)
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->scene_dirty = false;
+    ctx->bvh2_stale = false;
     return PT_OK;
 }
 
@@ -389,6 +450,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_refit, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void **)&ctx->d_work, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_stats, kStatsShards * kStatsStride * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipDeviceProp_t prop;
@@ -421,6 +483,9 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
+    free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
+    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes);
+    if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
     free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -472,7 +537,32 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
             objects[o].indices_count != ctx->objects[o].indices_count)
             return fail(ctx, PT_ERR_INVALID, "pt_update_transforms: index ranges differ from pt_set_meshes");
     ctx->objects.assign(objects, objects + n_objects);
-    ctx->scene_dirty = true;
+    if (!ctx->refit || !ctx->refit_ready || ctx->scene_dirty || ctx->bvh_width != 4 || n_objects == 0) {
+        ctx->scene_dirty = true;      // full build at the next render
+        return PT_OK;
+    }
+    // ---- refit on the device: new matrices in, boxes redone bottom-up, all ordered on the context's stream
+    DeviceGuard g(ctx->device);
+    auto t0 = std::chrono::steady_clock::now();
+    if (ctx->refit_in_flight) { PT_HIP(ctx, hipEventSynchronize(ctx->ev_refit)); ctx->refit_in_flight = false; }   // d_matrices is free again
+    std::vector<float> mats((size_t)n_objects * 16);
+    for (int o = 0; o < n_objects; o++) std::memcpy(&mats[(size_t)o * 16], objects[o].local_to_world, 64);
+    PT_HIP(ctx, hipMemcpy(ctx->d_matrices, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
+    RefitArgs ra;
+    ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
+    ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
+    ra.pad = ctx->box_pad; ra.n_prims = ctx->n_prims;
+    hipLaunchKernelGGL(refit_prims_kernel, dim3((ctx->n_prims + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra);
+    for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
+        const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
+        if (count > 0)
+            hipLaunchKernelGGL(refit_nodes_kernel, dim3((count + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra, first, count);
+    }
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventRecord(ctx->ev_refit, ctx->stream));
+    ctx->refit_in_flight = true;
+    ctx->bvh2_stale = true;
+    ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
 }
 
@@ -555,6 +645,7 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode 0 filters across pixels and renders whole frames only");
     DeviceGuard g(ctx->device);
     int rc;
+    if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
     if (ctx->scene_dirty) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if ((rc = rebuild_scene(ctx))) return rc;
@@ -661,6 +752,12 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         ctx->bvh_width = value;
         return PT_OK;
     }
+    if (std::strcmp(name, "refit") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: refit must be 0 or 1");
+        if (value && !ctx->refit) ctx->scene_dirty = true;   // the refit buffers are made by a full build
+        ctx->refit = value;
+        return PT_OK;
+    }
     if (std::strcmp(name, "refill_threshold") == 0) {
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_INVALID, "pt_set_option: refill_threshold must be 1..64");
         ctx->refill_threshold = value;
@@ -757,6 +854,7 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     DeviceGuard g(ctx->device);
     int rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
     if (ctx->scene_dirty && (rc = rebuild_scene(ctx))) return rc;
     float *d_od = nullptr, *d_t = nullptr; int32_t *d_id = nullptr;
     auto cleanup = [&] { free_dev(d_od); free_dev(d_t); free_dev(d_id); };

@@ -222,6 +222,54 @@ def test_update_transforms(tracer, sky_small):
         tracer.update_transforms(objs[:0])
 
 
+def _rot_y(deg, t=(0, 0, 0), scale=1.0):
+    a = np.radians(deg)
+    m = np.array([[np.cos(a) * scale, 0, np.sin(a) * scale, t[0]], [0, scale, 0, t[1]],
+                  [-np.sin(a) * scale, 0, np.cos(a) * scale, t[2]], [0, 0, 0, 1]], np.float32)
+    return m.T.reshape(16)      # Matrix4x4 memory order
+
+
+def test_refit_follows_moving_objects(tracer, sky_small):
+    """pt_update_transforms on a built scene refits the tree on the device (no host build).  Three objects that
+    share one mesh move for several frames - rotation, a large translation that inflates the root, a scale
+    change; every frame equals the oracle's render of the moved scene bit for bit, the tree still returns the
+    hit of the exhaustive loop, and a forced full build gives the same image."""
+    f = pa.Scene("fixture")
+    n_idx = len(f.indices)
+    objs = np.zeros(3, dtype=f.objects.dtype)
+    for k in range(3):
+        objs[k] = (_rot_y(0, (-3.0 + 3.0 * k, 0.0, 2.0 * k)), 0, n_idx)
+    tracer.set_spheres(f.spheres); tracer.set_meshes(objs, f.vertices, f.indices); tracer.set_sky(sky_small)
+    W, H = 96, 54
+    tracer.resize(W, H)
+    cam = dict(eye=(0, 5, -12), target=(0, 1, 2), fov=60)
+    p = pa.make_params(f, W, H, spp=1, max_bounces=4, seed=0.3, **cam)
+    tracer.render(p); tracer.sync()                                  # full build happens here
+    rng = np.random.default_rng(5)
+    for frame in range(4):
+        moved = objs.copy()
+        moved["m"][0] = _rot_y(20.0 * (frame + 1), (-3.0, 0.2 * frame, 0.0))
+        moved["m"][1] = _rot_y(-35.0 * frame, (0.0 + 1.5 * frame, 0.0, 2.0 + 10.0 * (frame == 2)))   # frame 2: far away
+        moved["m"][2] = _rot_y(10.0, (3.0, 0.0, 4.0), scale=1.0 + 0.25 * frame)
+        tracer.update_transforms(moved)
+        tracer.render(p)
+        g = tracer.read_result(); gid = tracer.read_hit_ids()
+        c, cid, _ = po.Oracle(f.spheres, moved, f.vertices, f.indices, sky=sky_small).render(p, W, H, threads=4)
+        assert (gid == cid).all(), f"frame {frame}"
+        _assert_same_image(g, c, f"refit frame {frame}")
+        o = rng.uniform(-8, 8, (200, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.5, 8, 200)
+        d = rng.normal(size=(200, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        od = np.concatenate([o, d], 1)
+        ib, tb = tracer.trace_rays(od); ie, te = tracer.trace_rays(od, brute_force=True)
+        assert (ib == ie).all() and (_bits(tb) == _bits(te)).all()
+    assert (gid > len(f.spheres)).any()
+    tracer.set_option("refit", 0)
+    tracer.update_transforms(moved)                                  # now a full host build at the next render
+    tracer.render(p)
+    _assert_same_image(tracer.read_result(), g, "rebuild after refits")
+    tracer.set_option("refit", 1)
+
+
 def test_caller_owned_targets_and_stream(tracer, fixture_scene):
     import torch
     s, orc = fixture_scene
