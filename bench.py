@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 NODE_BYTES = 56      # one four-wide BVH node as fetched: origin, exponents, 4 links, 4 x 6 plane bytes (csrc/bvh.hpp)
 PRIM_BYTES = 48      # one primitive record: v0, e1, e2 (+ id, kind)
-PIXEL_BYTES = 16     # RGBA32F result write per pixel
+PIXEL_BYTES = 48     # per pixel: RGBA32F Result write + accumulation buffer read and write
 HBM_PEAK_GBS = 8000.0
 
 
@@ -120,32 +120,31 @@ def main():
     tr.load_scene(scene, sky)
     tr.resize(W, H)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # this rank's fresh frame ("Result")
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # rank 0: sum over steps and ranks
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # this rank's sum over its steps ("Result1")
     tr.bind_target(pa.PT_TARGET_RESULT, frame.data_ptr())
+    tr.bind_target(pa.PT_TARGET_CONVERGED, accum.data_ptr())
     tr.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    def step(k):
-        # sample index of this rank in step k: k*world + rank  -> its own seed
-        p = pa.make_params(scene, W, H, seed=pa.frame_seed(k * world + rank), spp=args.spp, max_bounces=args.bounces)
-        tr.render(p)
+    def run(first, count):
+        """`count` steps: every rank adds its frames into its own accumulation buffer inside the kernel's final write
+        (sample indices first*world + rank, ... -> distinct seeds), then ONE sum-reduce of the buffers to rank 0."""
+        for j in range(count):
+            p = pa.make_params(scene, W, H, seed=pa.frame_seed((first + j) * world + rank), spp=args.spp,
+                               max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=j)
+            tr.render(p)
         if dist is not None:
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            accum.add_(frame)
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    run(0, args.warmup)             # also warms the collective up
     fence()
-    accum.zero_()
     tr.stats()                      # close the statistics epoch of the warm-up
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
+    run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     st = tr.stats()
@@ -173,7 +172,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} ({scene.n_triangles} triangles + {len(scene.spheres)} spheres + ground plane, "
                                    f"2048x1024 procedural sky) {W}x{H}, {args.bounces} bounces, {args.spp} spp per GPU per step",
-                       "parallelism": f"spp-sharded x{world}, scene replicated, RCCL sum-reduce of the frame per step"
+                       "parallelism": f"spp-sharded x{world}, scene replicated, in-kernel accumulation per GPU, one RCCL sum-reduce of the accumulation buffers per job"
                        if world > 1 else "single GPU",
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
