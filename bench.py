@@ -284,14 +284,39 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
             frame(3 + k)
         t.sync()
         return (time.perf_counter() - t0) / frames * 1e3
+    def run_stripes(mode, divisions=10):
+        old = []
+        def frame(k):
+            nonlocal old
+            c = k % divisions
+            if old:
+                t.set_camera_history(old)
+            t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k),
+                                    render_mode=mode, divisions=divisions, counter=c))
+            if c == 0:
+                old = []
+            old.append(pa.camera_history_entry(cam(k), scene.target, scene.fov, W / H))
+        t.set_camera_history([])
+        for k in range(divisions):
+            frame(k)
+        t.sync()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            frame(divisions + k)
+        t.sync()
+        return (time.perf_counter() - t0) / frames * 1e3
     plain = run(1)
     ms2 = run(2)
     ms0 = run(0)
     shown = t.read_result()
+    ms5 = run_stripes(5)
+    ms6 = run_stripes(6)
     t.close()
-    return {"ms_per_frame": ms2, "plain_ms_per_frame": plain, "denoise_mode_ms_per_frame": ms0, "frames": frames,
+    return {"ms_per_frame": ms2, "plain_ms_per_frame": plain, "denoise_mode_ms_per_frame": ms0,
+            "stripes_ms_per_frame": ms5, "stripes_depth_ms_per_frame": ms6, "frames": frames,
             "denoise_mode_image_mean": float(shown[..., :3].mean()),
-            "config": "bench scene, 1920x1080, 1 spp, 4 bounces, _AccumulationFrames 10, 1 GPU; renderMode 2 / 1 / 0"}
+            "config": "bench scene, 1920x1080, 1 spp, 4 bounces, _AccumulationFrames 10, 1 GPU; renderMode 2 / 1 / 0; "
+                      "renderMode 5 / 6 with 10 stripes (one path-traced per frame, the others reprojected)"}
 
 
 if __name__ == "__main__":

@@ -87,14 +87,17 @@ typedef struct PtFrameParams {
                                             (RayTracingShader.compute:866-873); must be >= 1     */
     int32_t depth;                       /* _Depth                    RayTracingMaster.cs:532     */
     int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735,977-990): 1 = Default,
-                                            2 = Reproj, 0 = Denoise; the others are PT_ERR_UNSUPPORTED */
+                                            2 = Reproj, 0 = Denoise, 5 = PartialFrameReproj,
+                                            6 = PartialFrameReprojDepth; the others are PT_ERR_UNSUPPORTED */
     uint32_t sample_index;               /* _Sample of AddMat.shader:42 (RayTracingMaster.cs:805) */
     int32_t accumulate;                  /* PT_ACCUM_*                                            */
     int32_t tile_x0, tile_y0;            /* sub-rectangle of the image this dispatch renders;     */
     int32_t tile_w, tile_h;              /*   tile_w == 0 or tile_h == 0 means the whole image    */
     float pixel_offset[2];               /* _PixelOffset      uploaded, unused (RayTracingShader.compute:21,842) */
     float directional_light[4];          /* _DirectionalLight uploaded, unused (RayTracingShader.compute:19)    */
-    int32_t accumulation_frames;         /* _AccumulationFrames (RayTracingMaster.cs:738); renderMode 2 only    */
+    int32_t accumulation_frames;         /* _AccumulationFrames (RayTracingMaster.cs:738); renderMode 0 and 2   */
+    int32_t divisions;                   /* _Divisions (RayTracingMaster.cs:736) and                            */
+    int32_t counter;                     /* _Counter = counter++ % divisions (:737); renderMode 5 and 6 only    */
 } PtFrameParams;
 
 /* One element of each of the four history arrays _CameraToWorldOld,
@@ -171,9 +174,11 @@ int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height);
 
 /* SetMatrixArray("_CameraInverseProjectionOld" / "_CameraToWorldOld" / "_WorldToCameraOld" /
  * "_CameraProjectionOld") (RayTracingMaster.cs:468-471,492-495): the cameras of earlier frames,
- * entry 0 first.  count 0..PT_MAX_CAMERA_HISTORY; entries the caller does not supply read as zero
- * matrices, which is what the shader's uniform arrays hold before the first upload (renderMode 2
- * then finds no valid reprojection and writes the fresh frame, as on the reference's first frame). */
+ * entry 0 first.  Like a write into the shader's uniform arrays, a call overwrites elements
+ * 0..count-1 and leaves the others as they were (the partial-frame modes rely on that: early in a
+ * cycle the tail still holds the previous cycle's cameras).  All elements start as zero matrices -
+ * renderMode 2 then finds no valid reprojection and writes the fresh frame, as on the reference's
+ * first frame - and count == 0 puts them back to that state.  count 0..PT_MAX_CAMERA_HISTORY. */
 int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int count);
 
 /* InitRenderTexture (RayTracingMaster.cs:542-583): allocate Result / converged
@@ -202,7 +207,16 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
  * the path tracer's reprojected radiance goes to Result2 (as renderMode 2 writes Result, plus the
  * thread-group row limit of :908-915); then Result = denoiser(Result1) (:479-615) for every pixel, then
  * Result = TAA(Result1, Result) (:644-714) for every pixel.  The shader runs all of it per thread without
- * a barrier; here each step is complete before the next starts.  Whole frames only. */
+ * a barrier; here each step is complete before the next starts.  Whole frames only.
+ *
+ * renderMode 5 / 6 (RayTracingShader.compute:742-789,933-936,1108-1112): the image is cut into
+ * `divisions` horizontal stripes; a dispatch path-traces stripe `counter` (rows y with
+ * H - s*(counter+1) <= y <= H - s*counter, s = H / divisions) exactly as renderMode 1 does and then
+ * copies it into Result1; every other pixel takes the bilinear sample of Result1 at the position where
+ * the camera that rendered ITS stripe (history element divisions - y/s - 1) saw the point 10 units along
+ * the pixel's current camera ray (mode 5) or the pixel's current primary hit (mode 6; a primary miss
+ * shows the sky), or (0,0,0,1) when that position is off screen.  Result1 is read as it was before the
+ * dispatch.  Whole frames only; accumulate must be PT_ACCUM_NONE. */
 int pt_render(pt_context *ctx, const PtFrameParams *params);
 
 int pt_sync(pt_context *ctx);

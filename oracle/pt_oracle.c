@@ -337,8 +337,9 @@ static int any3(f3 v) { return v.x != 0.0f || v.y != 0.0f || v.z != 0.0f; }
  * and NaN to 0, and a load outside the texture gives 0 (SH:450-453, SH:968); float s =
  * 1.0/textureSize keeps .x (SH:445); a*b+c is not fused. */
 typedef struct History {
-    const PtCameraHistory *cam;   /* entry 0 of the four *Old arrays */
+    const PtCameraHistory *cam;   /* the element of the four *Old arrays to use (entry 0 unless stated) */
     const float *result1;         /* Result1: W*H*4, the previous frame's Result */
+    const PtCameraHistory *all;   /* the whole arrays, PT_MAX_CAMERA_HISTORY elements (renderMode 5/6) */
 } History;
 
 static void find_camera_ray(const History *hs, int W, int H, f3 direction, float *uv_out) /* SH:394-411, framesFrom 0 */
@@ -472,7 +473,7 @@ static f3 lerp3(f3 a, f3 b, float t) { return pt_make3(a.x + t * (b.x - a.x), a.
 
 static f3 load_xyz_uint(const float *tex, int W, int H, float x, float y)        /* tex[float2]: operator[] */
 {
-    History hs = {NULL, tex};
+    History hs = {NULL, tex, NULL};
     float v[4];
     load_result1(&hs, W, H, x, y, v);
     return pt_make3(v[0], v[1], v[2]);
@@ -483,7 +484,7 @@ static f3 load_xyz_uint(const float *tex, int W, int H, float x, float y)       
  * writing it; here all of them have finished the denoiser and none has written the TAA output). */
 static void taa(const float *result1, const float *cur, int W, int H, float fx, float fy, float *out4)
 {
-    History hs = {NULL, result1};
+    History hs = {NULL, result1, NULL};
     float last[4];
     bilinear_texture_sample(&hs, W, H, fx, fy, last);                           /* SH:651 */
     f3 antialiased = pt_make3(last[0], last[1], last[2]);
@@ -529,6 +530,36 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
     float fw = (float)W, fh = (float)H;
     float u = (float)idx / fw * 2.0f - 1.0f;   /* SH:802, SH:842: pixel corner, no jitter */
     float v = (float)idy / fh * 2.0f - 1.0f;
+    if (prm->render_mode == 5 || prm->render_mode == 6) {   /* SH:742-789: pixels outside the stripe being rendered */
+        float stripe = fh / (float)prm->divisions;                                   /* SH:742 */
+        float fy = (float)idy;
+        if (fy > fh - stripe * (float)prm->counter || fy < fh - stripe * (float)(prm->counter + 1)) {   /* SH:751 */
+            Ray rayr = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);   /* SH:753-754 */
+            f3 hitPosr = pt_along3(rayr.origin, 10.0f, rayr.direction);              /* SH:755 */
+            if (prm->render_mode % 2 == 0) {                                         /* SH:757-764 */
+                RayHit hitr = trace(p, &rayr, cn);
+                cn->rays++; cn->paths++;
+                hitPosr = hitr.position;
+                if (!(hitr.distance < PT_INF)) {
+                    f3 sky = skybox_sample(p, &rayr);
+                    out4[0] = sky.x; out4[1] = sky.y; out4[2] = sky.z; out4[3] = 1.0f;
+                    return;
+                }
+            }
+            /* SH:766: (_Divisions - (id.y / stripe)) - 1 % _Divisions, a float, truncated into the int */
+            int framesBack = (int)(((float)prm->divisions - fy / stripe) - (float)(1 % prm->divisions));
+            if (framesBack < 0) framesBack = 0;                                      /* keep the index inside the arrays */
+            if (framesBack > PT_MAX_CAMERA_HISTORY - 1) framesBack = PT_MAX_CAMERA_HISTORY - 1;
+            History h = {&hs->all[framesBack], hs->result1, hs->all};
+            f3 originOld = pt_make3(h.cam->camera_to_world[12], h.cam->camera_to_world[13], h.cam->camera_to_world[14]);   /* SH:769 */
+            float reproUV[2];
+            find_camera_ray(&h, W, H, pt_sub3(hitPosr, originOld), reproUV);         /* SH:770 */
+            if (reproUV[0] < fw && reproUV[0] > 0 && reproUV[1] < fh && reproUV[1] > 0)
+                bilinear_texture_sample(&h, W, H, reproUV[0], reproUV[1], out4);     /* SH:776 */
+            else { out4[0] = out4[1] = out4[2] = 0.0f; out4[3] = 1.0f; }             /* SH:780 */
+            return;                                                                  /* SH:783-784 */
+        }
+    }
     if (prm->depth == 1) {                     /* SH:799-809 */
         Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
         RayHit hit = trace(p, &ray, cn);
@@ -616,21 +647,25 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
 {
     if (!p || !prm || !result || W <= 0 || H <= 0 || prm->max_bounces < 1) return 1;
     const int mode = prm->render_mode;
-    if (mode != 0 && mode != 1 && mode != 2) return 1;
+    const int stripes = mode == 5 || mode == 6;
+    if (mode != 0 && mode != 1 && mode != 2 && !stripes) return 1;
     if (mode != 1 && !result1) return 1;
     if (mode == 0 && !result2) return 1;
-    PtCameraHistory zero;
-    memset(&zero, 0, sizeof zero);               /* uniform arrays never uploaded hold zeros */
-    History hs = {n_history > 0 && history ? &history[0] : &zero, result1};
+    if (stripes && (prm->divisions < 1 || prm->divisions > PT_MAX_CAMERA_HISTORY || prm->counter < 0 || prm->counter >= prm->divisions)) return 1;
+    /* the four uniform arrays: elements never uploaded hold zeros */
+    PtCameraHistory *cams = (PtCameraHistory *)calloc(PT_MAX_CAMERA_HISTORY, sizeof(PtCameraHistory));
+    if (!cams) return 1;
+    if (history && n_history > 0) memcpy(cams, history, sizeof(PtCameraHistory) * (size_t)(n_history < PT_MAX_CAMERA_HISTORY ? n_history : PT_MAX_CAMERA_HISTORY));
+    History hs = {&cams[0], result1, cams};
     int x0 = 0, y0 = 0, tw = W, th = H;
     if (prm->tile_w > 0 && prm->tile_h > 0) { x0 = prm->tile_x0; y0 = prm->tile_y0; tw = prm->tile_w; th = prm->tile_h; }
-    if (x0 < 0 || y0 < 0 || x0 + tw > W || y0 + th > H) return 1;
-    if (mode == 0 && (tw != W || th != H)) return 1;   /* the denoiser and TAA read neighbours: whole frames only */
+    if (x0 < 0 || y0 < 0 || x0 + tw > W || y0 + th > H) { free(cams); return 1; }
+    if ((mode == 0 || stripes) && (tw != W || th != H)) { free(cams); return 1; }   /* these modes read across pixels: whole frames only */
     if (threads <= 0) threads = 1;
     const int screen_passes = mode == 0 && prm->depth != 1 && prm->samples_per_pixel > 0;
     /* SH:728-736 for every dispatched thread, before any of them goes on:
      * Result1 = Result (renderMode 2) or Result1 = Result2 (renderMode 0) */
-    if (mode != 1) {
+    if (mode == 0 || mode == 2) {
         const float *src = mode == 0 ? result2 : result;
         for (int y = y0; y < y0 + th; y++)
             memcpy(result1 + 4 * ((size_t)y * W + x0), src + 4 * ((size_t)y * W + x0), (size_t)tw * 4 * sizeof(float));
@@ -639,7 +674,7 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
     if (screen_passes) {
         seeds = (float *)malloc((size_t)W * H * sizeof(float));
         denoised = (float *)malloc((size_t)W * H * 4 * sizeof(float));
-        if (!seeds || !denoised) { free(seeds); free(denoised); return 1; }
+        if (!seeds || !denoised) { free(seeds); free(denoised); free(cams); return 1; }
     }
     /* the path tracer; renderMode 0 writes its (reprojected) radiance to Result2, SH:912-924 */
     float *trace_out = (mode == 0 && prm->depth != 1) ? result2 : result;
@@ -667,6 +702,17 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
                 taa(result1, denoised, W, H, (float)x, (float)y, result + 4 * ((size_t)y * W + x));
         free(seeds); free(denoised);
     }
+    if (stripes && prm->depth != 1) {
+        /* SH:1108-1112: Result1 = Result for the pixels of the rendered stripe - the only threads that get that
+         * far - once every pixel above has read the Result1 of before the dispatch */
+        float fh = (float)H, stripe = fh / (float)prm->divisions;
+        for (int y = 0; y < H; y++) {
+            float fy = (float)y;
+            if (fy > fh - stripe * (float)prm->counter || fy < fh - stripe * (float)(prm->counter + 1)) continue;
+            memcpy(result1 + 4 * (size_t)y * W, result + 4 * (size_t)y * W, (size_t)W * 4 * sizeof(float));
+        }
+    }
+    free(cams);
     if (stats) { stats->trace_calls = a; stats->rays = b; stats->paths = c; stats->prims_tested = d; }
     return 0;
 }
@@ -853,13 +899,13 @@ int pto_path_dump(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, 
 
 void pto_find_camera_ray(const PtCameraHistory *old_camera, int W, int H, const float *dir3, float *uv2)
 {
-    History hs = {old_camera, NULL};
+    History hs = {old_camera, NULL, NULL};
     find_camera_ray(&hs, W, H, pt_make3(dir3[0], dir3[1], dir3[2]), uv2);
 }
 
 void pto_bilinear_sample(const float *result1, int W, int H, float px, float py, float *out4)
 {
-    History hs = {NULL, result1};
+    History hs = {NULL, result1, NULL};
     bilinear_texture_sample(&hs, W, H, px, py, out4);
 }
 

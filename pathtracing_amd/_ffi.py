@@ -26,7 +26,8 @@ class PtFrameParams(C.Structure):
                 ("depth", C.c_int32), ("render_mode", C.c_int32), ("sample_index", C.c_uint32),
                 ("accumulate", C.c_int32), ("tile_x0", C.c_int32), ("tile_y0", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("pixel_offset", C.c_float * 2),
-                ("directional_light", C.c_float * 4), ("accumulation_frames", C.c_int32)]
+                ("directional_light", C.c_float * 4), ("accumulation_frames", C.c_int32),
+                ("divisions", C.c_int32), ("counter", C.c_int32)]
 
 
 class PtCameraHistory(C.Structure):
@@ -96,6 +97,7 @@ PTMASTER_SYMBOLS = {
     "ptm_master_load_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "ptm_master_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]),
     "ptm_master_set_render_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptm_master_set_divisions": (C.c_int, [C.c_void_p, C.c_int]),
     "ptm_master_set_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "ptm_master_render": (C.c_int, [C.c_void_p]),
     "ptm_master_peek_params": (C.c_int, [C.c_void_p, _P(PtFrameParams)]),

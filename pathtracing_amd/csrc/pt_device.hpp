@@ -37,7 +37,7 @@ struct RenderArgs {
     float c2w[16];
     float ip[16];
     float seed;
-    int32_t spp, maxb, depth;
+    int32_t spp, maxb, depth;     // depth: _Depth (0 / 1), or 2 = write the primary hit's t to seed_out and nothing else
     int32_t W, H;
     int32_t tx0, ty0, tw, th;     // tile rectangle
     int32_t tiles_x;              // 8x8 pixel blocks per row of the tile rectangle
@@ -702,6 +702,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                     float dis = tbest / 16.0f;
                     a.result[p] = make_float4(dis, dis, dis, dis);
                     if (a.hit_ids) a.hit_ids[p] = idbest;
+                    finished = true;
+                } else if (a.depth == 2) {                            // primary hit only, for stripe_reproject_kernel (SH:757-759)
+                    a.seed_out[(size_t)pix_y * a.W + pix_x] = tbest;
                     finished = true;
                 } else {
                     const float4 s0 = *ls0, s1 = *ls1;

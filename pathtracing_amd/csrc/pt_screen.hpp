@@ -142,4 +142,64 @@ __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void taa_kernel(cons
     a.result[(size_t)y * a.W + x] = make_float4(aa.x, aa.y, aa.z, mixRate);                  // SH:713, SH:929
 }
 
+// ---- renderMode 5 / 6: pixels outside the stripe being rendered (SH:742-789) ----
+
+struct StripeArgs {
+    const PtCameraHistory *cams;   // the four *Old arrays, PT_MAX_CAMERA_HISTORY elements
+    const float *t_primary;        // renderMode 6: t of every pixel's primary hit (+inf = miss)
+    int32_t divisions, counter, mode;
+};
+
+// FindCameraRay(input, framesFrom) (SH:394-411) against history element `cam`.
+__device__ __forceinline__ f2 find_camera_ray_in(const PtCameraHistory &cam, int W, int H, f3 dir)
+{
+    const float m11 = cam.camera_projection[5], m22 = cam.camera_projection[10], m23 = cam.camera_projection[14];
+    const float near = -m23 / m22;
+    const float far = -(near * m22) / (1.0f - m22);
+    const f3 pos = pt_scale3(pt_normalize3(dir), near + (far - near));
+    const float ratio = (float)((uint32_t)W / (uint32_t)H);
+    const f3 toCam = pt_mul_dir(cam.world_to_camera, pos);
+    const float height = toCam.z / m11;
+    const float width = ratio * height;
+    const float dimx = (float)W, dimy = (float)H;
+    const float uvx = (toCam.x - width * (dimx / dimy)) / width;
+    const float uvy = (toCam.y - height) / height;
+    f2 r;
+    r.x = 0.5f - uvx * (dimy * ratio / 2.0f);
+    r.y = (0.5f - uvy * (dimy / 2.0f)) - 0.005f;
+    return r;
+}
+
+// One thread per pixel; pixels of the stripe being path-traced are left alone.
+__global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void stripe_reproject_kernel(const RenderArgs a, const StripeArgs sa)
+{
+    const int x = blockIdx.x * kScreenBlockX + threadIdx.x, y = blockIdx.y * kScreenBlockY + threadIdx.y;
+    if (x >= a.W || y >= a.H) return;
+    const float fh = (float)a.H, fy = (float)y;
+    const float stripe = fh / (float)sa.divisions;                                            // SH:742
+    if (!(fy > fh - stripe * (float)sa.counter || fy < fh - stripe * (float)(sa.counter + 1))) return;   // SH:751
+    const size_t p = (size_t)y * a.W + x;
+    f3 o, d;
+    camera_ray(a, x, y, o, d);                                                                // SH:753-754
+    f3 hit_pos = pt_along3(o, 10.0f, d);                                                      // SH:755
+    if (sa.mode % 2 == 0) {                                                                   // SH:757-764
+        const float t = sa.t_primary[p];
+        if (!(t < PT_INF)) {
+            const f3 sky = sky_sample(a.sc, d);
+            a.result[p] = make_float4(sky.x, sky.y, sky.z, 1.0f);
+            return;
+        }
+        hit_pos = pt_along3(o, t, d);
+    }
+    const int one_mod = 1 % sa.divisions;
+    int frames_back = (int)(((float)sa.divisions - fy / stripe) - (float)one_mod);            // SH:766
+    frames_back = frames_back < 0 ? 0 : frames_back > PT_MAX_CAMERA_HISTORY - 1 ? PT_MAX_CAMERA_HISTORY - 1 : frames_back;   // stay inside the arrays
+    const PtCameraHistory &cam = sa.cams[frames_back];
+    const f3 origin_old = pt_make3(cam.camera_to_world[12], cam.camera_to_world[13], cam.camera_to_world[14]);
+    const f2 uv = find_camera_ray_in(cam, a.W, a.H, pt_sub3(hit_pos, origin_old));            // SH:770
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                         // SH:780
+    if (uv.x < (float)a.W && uv.x > 0.0f && uv.y < (float)a.H && uv.y > 0.0f) out = bilinear_history(a, uv);   // SH:772-776
+    a.result[p] = out;
+}
+
 }  // namespace ptrace

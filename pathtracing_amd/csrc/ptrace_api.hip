@@ -33,7 +33,9 @@ struct pt_context {
     std::vector<float> vertices;
     std::vector<int32_t> indices;
     bool scene_dirty = true;
-    std::vector<PtCameraHistory> camera_history;   // pt_set_camera_history
+    std::vector<PtCameraHistory> camera_history = std::vector<PtCameraHistory>(PT_MAX_CAMERA_HISTORY);   // the four *Old arrays; zero-initialised
+    PtCameraHistory *d_cams = nullptr;             // device copy for the partial-frame modes
+    bool cams_dirty = true;
 
     // refit state (pt_refit.hpp): what pt_update_transforms needs to redo boxes without a host build
     int refit = 1;                                 // option "refit"
@@ -484,7 +486,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
-    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes);
+    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_cams);
     if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
     free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -626,23 +628,63 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
     return PT_OK;
 }
 
+// Path-trace the rectangle (x0, y0, tw, th) with the arguments in `a` (everything but the tile fields filled in).
+static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, int th)
+{
+    if (tw <= 0 || th <= 0) return PT_OK;
+    int rc;
+    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th;
+    a.tiles_x = (tw + 7) / 8;
+    const int tiles_y = (th + 7) / 8;
+    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1) return render_wavefront(ctx, a);
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
+    int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
+    int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->sched_blocks_per_cu);
+    if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
+    a.stack_overflow = ctx->d_stack_ovf;
+    a.lane_state = ctx->d_lane_state;
+    a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
+    if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// Scratch of the screen-space passes: one float4 and one float per pixel.
+static int ensure_screen_scratch(pt_context *ctx)
+{
+    if (ctx->screen_pixels >= (size_t)ctx->W * ctx->H) return PT_OK;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
+    ctx->screen_pixels = 0;
+    PT_HIP(ctx, hipMalloc((void **)&ctx->d_filtered, (size_t)ctx->W * ctx->H * sizeof(float4)));
+    PT_HIP(ctx, hipMalloc((void **)&ctx->d_seeds, (size_t)ctx->W * ctx->H * sizeof(float)));
+    ctx->screen_pixels = (size_t)ctx->W * ctx->H;
+    return PT_OK;
+}
+
 int pt_render(pt_context *ctx, const PtFrameParams *p)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_render: params is NULL");
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_render before pt_resize");
-    if (p->render_mode != 0 && p->render_mode != 1 && p->render_mode != 2)
-        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 0 (Denoise), 1 (Default) and 2 (Reproj) are implemented");
-    if (p->render_mode != 1 && p->accumulate != PT_ACCUM_NONE)
-        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 0 and 2 use the converged target as their history; accumulate must be PT_ACCUM_NONE");
+    const int mode = p->render_mode;
+    const bool stripes = mode == 5 || mode == 6;
+    if (mode != 0 && mode != 1 && mode != 2 && !stripes)
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 0 (Denoise), 1 (Default), 2 (Reproj), 5 and 6 (PartialFrameReproj[Depth]) are implemented");
+    if (mode != 1 && p->accumulate != PT_ACCUM_NONE)
+        return fail(ctx, PT_ERR_INVALID, "pt_render: every renderMode but 1 uses the converged target as its history; accumulate must be PT_ACCUM_NONE");
     if (p->max_bounces < 1) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be >= 1");
     if (p->accumulate < PT_ACCUM_NONE || p->accumulate > PT_ACCUM_ADDMAT) return fail(ctx, PT_ERR_INVALID, "pt_render: bad accumulate mode");
     int x0 = 0, y0 = 0, tw = ctx->W, th = ctx->H;
     if (p->tile_w > 0 && p->tile_h > 0) { x0 = p->tile_x0; y0 = p->tile_y0; tw = p->tile_w; th = p->tile_h; }
     if (x0 < 0 || y0 < 0 || (int64_t)x0 + tw > ctx->W || (int64_t)y0 + th > ctx->H)
         return fail(ctx, PT_ERR_INVALID, "pt_render: tile outside the image");
-    if (p->render_mode == 0 && (tw != ctx->W || th != ctx->H))
-        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode 0 filters across pixels and renders whole frames only");
+    if ((mode == 0 || stripes) && (tw != ctx->W || th != ctx->H))
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode 0, 5 and 6 read across pixels and render whole frames only");
+    if (stripes && (p->divisions < 1 || p->divisions > PT_MAX_CAMERA_HISTORY || p->counter < 0 || p->counter >= p->divisions))
+        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 5/6 need 1 <= divisions <= 100 and 0 <= counter < divisions");
     DeviceGuard g(ctx->device);
     int rc;
     if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
@@ -650,50 +692,35 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if ((rc = rebuild_scene(ctx))) return rc;
     }
-    if (p->render_mode != 1) {
+    const size_t pitch = (size_t)ctx->W * sizeof(float4);
+    if (mode == 0 || mode == 2) {
         // SH:728-736, Result1 = Result (renderMode 2) or Result2 (renderMode 0) over the dispatched rectangle,
         // finished before any pixel is traced
-        const float4 *src = p->render_mode == 0 ? ctx->result2 : ctx->result;
-        const size_t pitch = (size_t)ctx->W * sizeof(float4);
+        const float4 *src = mode == 0 ? ctx->result2 : ctx->result;
         PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)y0 * ctx->W + x0, pitch, src + (size_t)y0 * ctx->W + x0, pitch,
                                      (size_t)tw * sizeof(float4), (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (p->depth != 1 && p->samples_per_pixel <= 0) return PT_OK;  // the shader's sample loop does not run
-    const bool screen_passes = p->render_mode == 0 && p->depth != 1;
-    if (screen_passes && ctx->screen_pixels < (size_t)ctx->W * ctx->H) {
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
-        ctx->screen_pixels = 0;
-        PT_HIP(ctx, hipMalloc((void **)&ctx->d_filtered, (size_t)ctx->W * ctx->H * sizeof(float4)));
-        PT_HIP(ctx, hipMalloc((void **)&ctx->d_seeds, (size_t)ctx->W * ctx->H * sizeof(float)));
-        ctx->screen_pixels = (size_t)ctx->W * ctx->H;
-    }
+    const bool no_samples = p->depth != 1 && p->samples_per_pixel <= 0;   // the shader's sample loop does not run
+    if (no_samples && !stripes) return PT_OK;
+    const bool screen_passes = mode == 0 && p->depth != 1;
+    if ((screen_passes || mode == 6) && (rc = ensure_screen_scratch(ctx))) return rc;
 
     RenderArgs a;
     a.sc = scene_dev(ctx);
     std::memcpy(a.c2w, p->camera_to_world, sizeof a.c2w);
     std::memcpy(a.ip, p->camera_inverse_projection, sizeof a.ip);
-    a.seed = p->seed; a.spp = p->samples_per_pixel; a.maxb = p->max_bounces; a.depth = p->depth;
+    a.seed = p->seed; a.spp = p->samples_per_pixel; a.maxb = p->max_bounces; a.depth = p->depth == 1 ? 1 : 0;
     a.W = ctx->W; a.H = ctx->H;
-    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th;
-    a.tiles_x = (tw + 7) / 8;
-    const int tiles_y = (th + 7) / 8;
-    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th; a.tiles_x = 0; a.total_items = 0;
     a.result = ctx->result; a.converged = ctx->conv; a.hit_ids = ctx->ids;
     a.accumulate = p->accumulate; a.sample_index = p->sample_index;
     a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
-    a.render_mode = p->render_mode;
+    a.render_mode = stripes ? 1 : mode;   // the stripe being rendered is written as renderMode 1 writes (SH:933-936)
     a.history = ctx->conv;
     a.accumulation_frames = (float)p->accumulation_frames;
-    {
-        // an entry that was never uploaded reads as zeros, like the shader's uniform arrays
-        PtCameraHistory h0;
-        std::memset(&h0, 0, sizeof h0);
-        if (!ctx->camera_history.empty()) h0 = ctx->camera_history[0];
-        std::memcpy(a.old_c2w, h0.camera_to_world, sizeof a.old_c2w);
-        std::memcpy(a.old_w2c, h0.world_to_camera, sizeof a.old_w2c);
-        std::memcpy(a.old_proj, h0.camera_projection, sizeof a.old_proj);
-    }
+    std::memcpy(a.old_c2w, ctx->camera_history[0].camera_to_world, sizeof a.old_c2w);
+    std::memcpy(a.old_w2c, ctx->camera_history[0].world_to_camera, sizeof a.old_w2c);
+    std::memcpy(a.old_proj, ctx->camera_history[0].camera_projection, sizeof a.old_proj);
     a.result2 = ctx->result2; a.seed_out = ctx->d_seeds;
 
     if (!ctx->epoch_open) {
@@ -701,19 +728,39 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         PT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->epoch_open = true;
     }
-    if (ctx->backend == 1 && a.depth != 1 && a.render_mode == 1) {
-        if ((rc = render_wavefront(ctx, a))) return rc;
-    } else {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
-        int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-        int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->sched_blocks_per_cu);
-        if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
-        a.stack_overflow = ctx->d_stack_ovf;
-        a.lane_state = ctx->d_lane_state;
-        a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
-        if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    if (stripes) {
+        // rows of the stripe being rendered: the shader's own float comparisons (SH:742,751), row by row
+        const float fh = (float)ctx->H, stripe = fh / (float)p->divisions;
+        int s_lo = ctx->H, s_hi = -1;
+        for (int y = 0; y < ctx->H; y++) {
+            const float fy = (float)y;
+            if (!(fy > fh - stripe * (float)p->counter || fy < fh - stripe * (float)(p->counter + 1))) { s_lo = std::min(s_lo, y); s_hi = std::max(s_hi, y); }
+        }
+        const int s_rows = s_hi >= s_lo ? s_hi - s_lo + 1 : 0;
+        if (!ctx->d_cams) PT_HIP(ctx, hipMalloc((void **)&ctx->d_cams, sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY));
+        if (ctx->cams_dirty) {
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // an earlier frame may still read the old values
+            PT_HIP(ctx, hipMemcpy(ctx->d_cams, ctx->camera_history.data(), sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY, hipMemcpyHostToDevice));
+            ctx->cams_dirty = false;
+        }
+        if (mode == 6) {
+            // SH:757-759: the other pixels' current primary hits, traced by the path kernel with nothing after the first hit
+            RenderArgs prim = a;
+            prim.depth = 2; prim.hit_ids = nullptr;
+            if ((rc = launch_path(ctx, prim, 0, 0, ctx->W, s_rows ? s_lo : ctx->H))) return rc;
+            if (s_rows && (rc = launch_path(ctx, prim, 0, s_hi + 1, ctx->W, ctx->H - s_hi - 1))) return rc;
+        }
+        StripeArgs sa;
+        sa.cams = ctx->d_cams; sa.t_primary = ctx->d_seeds; sa.divisions = p->divisions; sa.counter = p->counter; sa.mode = mode;
+        const dim3 blk(kScreenBlockX, kScreenBlockY), grd((ctx->W + kScreenBlockX - 1) / kScreenBlockX, (ctx->H + kScreenBlockY - 1) / kScreenBlockY);
+        hipLaunchKernelGGL(stripe_reproject_kernel, grd, blk, 0, ctx->stream, a, sa);
         PT_HIP(ctx, hipGetLastError());
+        if (s_rows && !no_samples && (rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
+        if (s_rows && p->depth != 1)   // SH:1108-1112, after every read of Result1 above
+            PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)s_lo * ctx->W, pitch, ctx->result + (size_t)s_lo * ctx->W, pitch,
+                                         (size_t)ctx->W * sizeof(float4), (size_t)s_rows, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        if ((rc = launch_path(ctx, a, x0, y0, tw, th))) return rc;
     }
     if (screen_passes) {
         // SH:928-929 as two launches: filter every pixel, then resolve every pixel
@@ -734,7 +781,9 @@ int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int c
     if (!ctx) return PT_ERR_INVALID;
     if (count < 0 || count > PT_MAX_CAMERA_HISTORY) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: count must be 0..100");
     if (count > 0 && !entries) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: entries is NULL");
-    ctx->camera_history.assign(entries, entries + count);
+    if (count == 0) std::memset(ctx->camera_history.data(), 0, sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY);
+    else std::memcpy(ctx->camera_history.data(), entries, sizeof(PtCameraHistory) * (size_t)count);
+    ctx->cams_dirty = true;
     return PT_OK;
 }
 

@@ -114,17 +114,21 @@ void RayTracingMaster::FillParams(PtFrameParams &p) const
     p.accumulate = (depth || renderMode != 1) ? PT_ACCUM_NONE : accumulate;
     p.sample_index = depth ? 0u : currentSample_;         // :805
     p.accumulation_frames = (int32_t)sampleFrames;        // :738
+    p.divisions = divisions;                              // :736
+    p.counter = divisions > 0 ? counter_ % divisions : 0; // :737 (the increment happens in Render)
 }
 
 int RayTracingMaster::SetShaderParameters(PtFrameParams &p)
 {
     FillParams(p);
-    // :492-495 - the history lists as they stand, i.e. the cameras of earlier frames
-    int rc = check(pt_set_camera_history(ctx_, oldCameras_.data(), (int)oldCameras_.size()), "pt_set_camera_history");
-    if (rc) return rc;
-    // :513-518 - outside the partial-frame modes the lists restart every frame (the partial-frame
-    // modes 5-8 keep `divisions` entries; they are not implemented, so the counter test is moot)
-    if (renderMode < 5 || renderMode > 8) oldCameras_.clear();
+    // :492-495 - the history lists as they stand, i.e. the cameras of earlier frames.  An empty list changes
+    // nothing (SetMatrixArray rejects it); a shorter one leaves the tail of the shader's arrays as it was.
+    if (!oldCameras_.empty()) {
+        int rc = check(pt_set_camera_history(ctx_, oldCameras_.data(), (int)oldCameras_.size()), "pt_set_camera_history");
+        if (rc) return rc;
+    }
+    // :513-518 - outside the partial-frame modes the lists restart every frame; inside them at the start of a cycle
+    if (renderMode < 5 || renderMode > 8 || (divisions > 0 && counter_ % divisions == 0)) oldCameras_.clear();
     // :520-526 - remember this frame's camera
     if (renderMode < 11 && renderMode != 1) {
         float e[3], t[3];
@@ -157,6 +161,7 @@ int RayTracingMaster::Render()
     if (targetW_ == 0 || targetH_ == 0) return PT_OK;     // :721
     if ((rc = check(pt_render(ctx_, &p), "pt_render"))) return rc;   // :735-747
     frame_++;
+    counter_++;                                           // :737
     // :885-888 - the sample counter saturates at sampleFrames, after which the blend is a moving average
     if (currentSample_ < sampleFrames) currentSample_++; else currentSample_ = sampleFrames;
     return PT_OK;
@@ -248,6 +253,7 @@ int ptm_master_configure(ptm_master *m, int width, int height, int spp, int max_
     return PT_OK;
 }
 int ptm_master_set_render_mode(ptm_master *m, int render_mode) { m->m->renderMode = render_mode; return PT_OK; }
+int ptm_master_set_divisions(ptm_master *m, int divisions) { m->m->divisions = divisions; return PT_OK; }
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov, float eye_offset)
 {
     std::memcpy(m->m->eye, eye, 12); std::memcpy(m->m->target, target, 12);

@@ -20,6 +20,7 @@ public:
     uint32_t sampleFrames = 3;                    // :74
     bool depth = false;                           // :686
     int renderMode = 1;                           // RenderMode.Default, :979
+    int divisions = 10;                           // :701
     int maxBounces = 4;                           // hard-coded in the shader, RayTracingShader.compute:867
     int accumulate = PT_ACCUM_NONE;               // the AddMat pass is dormant in the reference (:804-820)
 
@@ -48,6 +49,7 @@ public:
     void ResetAccumulation() { currentSample_ = 0; }    // :145, :753
     uint32_t currentSample() const { return currentSample_; }
     uint32_t frameIndex() const { return frame_; }
+    int counterValue() const { return counter_; }
 
 private:
     int SetUpScene(const Scene &scene);                 // :315-369 (sphere list comes from the Scene)
@@ -65,6 +67,7 @@ private:
     int targetW_ = 0, targetH_ = 0;                     // size of _target
     uint32_t currentSample_ = 0;                        // _currentSample :45
     uint32_t frame_ = 0;                                // frames dispatched; drives the per-frame _Seed
+    int counter_ = 0;                                   // counter :702
     std::vector<PtCameraHistory> oldCameras_;           // oldIPR / oldCTW / oldWTC / oldPRJ :450-453, one struct per entry
     void currentCamera(float e[3], float t[3]) const;   // eye and target with the stereo offset applied
 };

@@ -48,3 +48,46 @@ def gpu_sequence(tracer, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5
         out.append((tracer.read_result(), tracer.read_converged(), tracer.read_hit_ids(), tracer.stats())
                    + ((tracer.read_target(pa.PT_TARGET_DENOISED),) if mode0 else ()))
     return out
+
+
+# ---- renderMode 5 / 6: one stripe per frame, the rest reprojected (RayTracingMaster.cs:513-526, 736-737)
+
+def stripe_frames(scene, W, H, n_frames, divisions, mode, spp=1, max_bounces=4, step=(0.12, 0.05, 0.2)):
+    """Per frame: (PtFrameParams, the history list the host uploads before the dispatch)."""
+    old = []
+    out = []
+    for k in range(n_frames):
+        counter = k % divisions
+        eye, target = camera_at(scene, k, step)
+        p = pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=spp, max_bounces=max_bounces, eye=eye, target=target,
+                           render_mode=mode, divisions=divisions, counter=counter)
+        out.append((p, list(old)))
+        if counter == 0:
+            old = []
+        old.append(pa.camera_history_entry(eye, target, scene.fov, W / H))
+    return out
+
+
+def oracle_stripe_sequence(oracle, scene, W, H, n_frames, divisions, mode, threads=4, **kw):
+    result = np.zeros((H, W, 4), np.float32); result1 = np.zeros((H, W, 4), np.float32)
+    state = [pa.PtCameraHistory() for _ in range(100)]          # the shader's uniform arrays: a shorter upload keeps the tail
+    out = []
+    for p, hist in stripe_frames(scene, W, H, n_frames, divisions, mode, **kw):
+        state[:len(hist)] = hist
+        ids, st = oracle.render_history(p, state, W, H, result, result1, threads=threads)
+        out.append((result.copy(), result1.copy(), ids, st))
+    return out
+
+
+def gpu_stripe_sequence(tracer, scene, W, H, n_frames, divisions, mode, **kw):
+    for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED):
+        tracer.write_target(which, np.zeros((H, W, 4), np.float32))
+    tracer.set_camera_history([])                               # back to all-zero arrays
+    out = []
+    for p, hist in stripe_frames(scene, W, H, n_frames, divisions, mode, **kw):
+        if hist:
+            tracer.set_camera_history(hist)
+        tracer.stats()
+        tracer.render(p)
+        out.append((tracer.read_result(), tracer.read_converged(), None, tracer.stats()))
+    return out

@@ -300,7 +300,7 @@ def test_error_paths(tracer):
     for bad in (dict(max_bounces=0), dict(tile=(8, 8, 16, 16)), dict(accumulate=9)):
         with pytest.raises(pa.PtraceError):
             tracer.render(pa.make_params(s, 16, 16, **bad))
-    p = pa.make_params(s, 16, 16); p.render_mode = 0
+    p = pa.make_params(s, 16, 16); p.render_mode = 7
     with pytest.raises(pa.PtraceError, match="renderMode"):
         tracer.render(p)
     with pytest.raises(pa.PtraceError, match="outside"):
@@ -568,3 +568,52 @@ def test_denoise_mode_errors_and_depth(tracer):
     assert (tracer.read_result().view(np.uint32) == want.view(np.uint32)).all()   # SH:799-809 returns before the mode-0 block
     assert (tracer.read_converged() == marker).all()                              # but after Result1 = Result2 (SH:733-736)
     assert (tracer.read_target(pa.PT_TARGET_DENOISED) == marker).all()
+
+
+# ------------------------------------------- renderMode 5 / 6 (partial frames)
+
+@pytest.mark.parametrize("mode", [5, 6])
+def test_stripe_modes_match_oracle_bit_exact(tracer, mode):
+    """Six frames, four stripes per cycle, moving camera: the displayed frame and the history mosaic of every frame
+    equal the oracle's bit for bit; the camera arrays keep the previous cycle's tail."""
+    from reproj_util import gpu_stripe_sequence, oracle_stripe_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    W, H = 64, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_stripe_sequence(o, s, W, H, 6, 4, mode, spp=1, max_bounces=4)
+    got = gpu_stripe_sequence(tracer, s, W, H, 6, 4, mode, spp=1, max_bounces=4)
+    for k in range(6):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"Result1, frame {k}"
+        assert got[k][3]["rays"] == want[k][3]["rays"] and got[k][3]["paths"] == want[k][3]["paths"]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stripes_64x36.npz"))
+    assert (got[5][0].view(np.uint32) == g[f"mode{mode}_result5"].view(np.uint32)).all()
+    assert (got[5][1].view(np.uint32) == g[f"mode{mode}_result1_5"].view(np.uint32)).all()
+    assert (got[5][0][..., :3] > 0).mean() > 0.5                       # reprojection really fills the other stripes
+
+
+def test_stripe_modes_mesh_scene_uneven_rows(tracer):
+    """70 k triangles, 131x77 with 10 stripes: rows per stripe is not an integer, so which rows belong to a stripe
+    is decided by the shader's float comparisons."""
+    from reproj_util import gpu_stripe_sequence, oracle_stripe_sequence
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(256, 128)
+    W, H = 131, 77
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    for mode in (5, 6):
+        want = oracle_stripe_sequence(o, s, W, H, 12, 10, mode, spp=1, max_bounces=4, threads=8)
+        got = gpu_stripe_sequence(tracer, s, W, H, 12, 10, mode, spp=1, max_bounces=4)
+        for k in range(12):
+            assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"mode {mode} Result, frame {k}"
+            assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"mode {mode} Result1, frame {k}"
+
+
+def test_stripe_mode_errors(tracer):
+    s = pa.Scene("fixture")
+    W, H = 40, 24
+    tracer.load_scene(s, None); tracer.resize(W, H)
+    for kw in (dict(divisions=0, counter=0), dict(divisions=4, counter=4), dict(divisions=101, counter=0),
+               dict(divisions=4, counter=1, tile=(0, 0, 20, 10)), dict(divisions=4, counter=1, accumulate=pa.PT_ACCUM_MEAN)):
+        with pytest.raises(pa.PtraceError):
+            tracer.render(pa.make_params(s, W, H, render_mode=5, **kw))

@@ -491,3 +491,44 @@ def test_exp_accuracy():
     want = np.exp(xs.astype(np.float64))
     assert np.max(np.abs(got - want) / want) < 2e-5      # |x| * 2^-24 from rounding x*log2(e), plus the exp2 kernel
     assert po.fmath("exp", -0.0) == 1.0
+
+
+# ------------------------------------------- renderMode 5 / 6 (partial frames)
+
+@pytest.mark.parametrize("mode", [5, 6])
+def test_stripe_modes_properties(mode):
+    """One stripe of H/divisions rows is path-traced per frame exactly as renderMode 1 renders it and copied into
+    Result1; with a static camera every other pixel takes back (a bilinear tap of) what its own stripe rendered."""
+    from reproj_util import oracle_stripe_sequence, stripe_frames
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    W, H, D = 48, 40, 4
+    seq = oracle_stripe_sequence(o, s, W, H, 2 * D, D, mode, step=(0, 0, 0))
+    frames = stripe_frames(s, W, H, 2 * D, D, mode, step=(0, 0, 0))
+    stripe = H / D
+    for k, (res, res1, _, st) in enumerate(seq):
+        c = k % D
+        rows = [y for y in range(H) if not (y > H - stripe * c or y < H - stripe * (c + 1))]
+        assert rows == list(range(int(H - stripe * (c + 1)), min(H - 1, int(H - stripe * c)) + 1))   # both ends inclusive (SH:751)
+        p1 = pa.PtFrameParams.from_buffer_copy(frames[k][0]); p1.render_mode = 1
+        plain = o.render(p1, W, H)[0]
+        assert (res[rows] == plain[rows]).all()                    # SH:933-936
+        assert (res1[rows] == res[rows]).all()                     # SH:1108-1112
+        others = [y for y in range(H) if y not in rows]
+        if k == 0:
+            # nothing rendered yet and no cameras uploaded: off-screen value (SH:780) - or the sky in the depth variant
+            hit = (res[others][..., 3] == 1.0)
+            assert hit.all()
+            if mode == 5:
+                assert (res[others][..., :3] == 0).all()
+        paths = st["paths"]
+        assert paths == len(rows) * W + (len(others) * W if mode == 6 else 0)
+    # after a full cycle every stripe has been rendered once; with a static camera the reprojected pixels repeat what
+    # Result1 holds around their own position, so the displayed frame is close to a plain render of the scene
+    last = seq[-1][0]
+    p1 = pa.PtFrameParams.from_buffer_copy(frames[-1][0]); p1.render_mode = 1
+    plain = o.render(p1, W, H)[0]
+    ids = o.render(p1, W, H)[1]
+    interior = np.zeros((H, W), bool); interior[2:-2, 2:-2] = True
+    close = np.abs(last[..., 3] - plain[..., 3]) < 0.05 * np.maximum(plain[..., 3], 1e-3)
+    assert close[interior & (ids >= 0)].mean() > 0.8

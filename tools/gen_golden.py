@@ -64,3 +64,13 @@ for k, fr in enumerate(seq0):
     dn[f"result{k}"] = fr[0]; dn[f"result2_{k}"] = fr[4]
 np.savez_compressed(os.path.join(out, "denoise_64x36.npz"), **dn)
 print("wrote denoise_64x36.npz; mean of the displayed frame 2:", float(seq0[2][0][..., :3].mean()))
+
+# (x) renderMode 5 and 6: six frames, 4 stripes per cycle, moving camera; the displayed frame and the history mosaic
+from reproj_util import oracle_stripe_sequence  # noqa: E402
+
+st = {}
+for mode in (5, 6):
+    seqs = oracle_stripe_sequence(o, s, W, H, 6, 4, mode, spp=1, max_bounces=4)
+    st[f"mode{mode}_result5"] = seqs[5][0]; st[f"mode{mode}_result1_5"] = seqs[5][1]
+np.savez_compressed(os.path.join(out, "stripes_64x36.npz"), **st)
+print("wrote stripes_64x36.npz")
