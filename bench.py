@@ -6,9 +6,10 @@
 A step = one pass of the hot path over one frame of the workload: a 1920x1080
 image of the ~260 k-triangle hall scene, 8 bounces, --spp samples per pixel per
 GPU.  With N GPUs every rank renders its own --spp samples of the same image
-(different sample indices / seeds; the scene is replicated) and the per-rank
-frames are sum-reduced to rank 0 over RCCL each step: weak scaling, the
-BASELINE config "1024 spp sharded across 8 GPUs with RCCL reduce" cut into steps.
+(different sample indices / seeds; the scene is replicated), adds them into its
+own accumulation buffer inside the kernel's final write, and the job ends with
+one sum-reduce of those buffers to rank 0 over RCCL, inside the timed region:
+weak scaling - "many spp sharded across the GPUs with an RCCL reduce".
 
 Prints ONE JSON line (rank 0): metric Mrays/s = Trace() calls executed by the
 kernels (counted on the device) per second of wall time, summed over ranks.
