@@ -271,12 +271,18 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
     t.load_scene(scene, sky); t.resize(W, H)
     def cam(k):
         return (scene.eye[0] + 0.01 * k, scene.eye[1], scene.eye[2] + 0.02 * k)
+    # frame parameters and camera-history entries are built before the clock starts: the figure is the library's
+    # and the GPU's time per frame, not this script's struct packing
+    n_total = frames + 16
+    hist_entry = [pa.camera_history_entry(cam(k), scene.target, scene.fov, W / H) for k in range(n_total)]
+
     def run(mode):
+        prm = [pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k), render_mode=mode,
+                              accumulation_frames=10) for k in range(n_total)]
         def frame(k):
             if mode != 1:
-                t.set_camera_history([pa.camera_history_entry(cam(k - 1), scene.target, scene.fov, W / H)] if k else [])
-            t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k),
-                                    render_mode=mode, accumulation_frames=10))
+                t.set_camera_history([hist_entry[k - 1]] if k else [])
+            t.render(prm[k])
         for k in range(3):
             frame(k)
         t.sync()
@@ -285,18 +291,19 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
             frame(3 + k)
         t.sync()
         return (time.perf_counter() - t0) / frames * 1e3
+
     def run_stripes(mode, divisions=10):
+        prm = [pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k), render_mode=mode,
+                              divisions=divisions, counter=k % divisions) for k in range(n_total)]
         old = []
         def frame(k):
             nonlocal old
-            c = k % divisions
             if old:
                 t.set_camera_history(old)
-            t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k),
-                                    render_mode=mode, divisions=divisions, counter=c))
-            if c == 0:
+            t.render(prm[k])
+            if k % divisions == 0:
                 old = []
-            old.append(pa.camera_history_entry(cam(k), scene.target, scene.fov, W / H))
+            old.append(hist_entry[k])
         t.set_camera_history([])
         for k in range(divisions):
             frame(k)
@@ -306,6 +313,7 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
             frame(divisions + k)
         t.sync()
         return (time.perf_counter() - t0) / frames * 1e3
+
     plain = run(1)
     ms2 = run(2)
     ms0 = run(0)

@@ -34,7 +34,13 @@ struct pt_context {
     std::vector<int32_t> indices;
     bool scene_dirty = true;
     std::vector<PtCameraHistory> camera_history = std::vector<PtCameraHistory>(PT_MAX_CAMERA_HISTORY);   // the four *Old arrays; zero-initialised
-    PtCameraHistory *d_cams = nullptr;             // device copy for the partial-frame modes
+    // device copies for the partial-frame modes: a small ring, so that an upload never waits for the frame
+    // that still reads the previous copy (pinned staging buffer + device buffer + "last reader done" event each)
+    static constexpr int kCamRing = 4;
+    PtCameraHistory *h_cams[kCamRing] = {}, *d_cams[kCamRing] = {};
+    hipEvent_t ev_cams[kCamRing] = {};
+    bool cams_used[kCamRing] = {};
+    int cam_slot = 0;
     bool cams_dirty = true;
 
     // refit state (pt_refit.hpp): what pt_update_transforms needs to redo boxes without a host build
@@ -486,7 +492,12 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
-    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_cams);
+    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes);
+    for (int i = 0; i < pt_context::kCamRing; i++) {
+        free_dev(ctx->d_cams[i]);
+        if (ctx->h_cams[i]) (void)hipHostFree(ctx->h_cams[i]);
+        if (ctx->ev_cams[i]) (void)hipEventDestroy(ctx->ev_cams[i]);
+    }
     if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
     free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -737,10 +748,17 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
             if (!(fy > fh - stripe * (float)p->counter || fy < fh - stripe * (float)(p->counter + 1))) { s_lo = std::min(s_lo, y); s_hi = std::max(s_hi, y); }
         }
         const int s_rows = s_hi >= s_lo ? s_hi - s_lo + 1 : 0;
-        if (!ctx->d_cams) PT_HIP(ctx, hipMalloc((void **)&ctx->d_cams, sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY));
-        if (ctx->cams_dirty) {
-            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // an earlier frame may still read the old values
-            PT_HIP(ctx, hipMemcpy(ctx->d_cams, ctx->camera_history.data(), sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY, hipMemcpyHostToDevice));
+        constexpr size_t cam_bytes = sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY;
+        if (ctx->cams_dirty || !ctx->d_cams[ctx->cam_slot]) {
+            const int i = ctx->cam_slot = (ctx->cam_slot + 1) % pt_context::kCamRing;
+            if (!ctx->d_cams[i]) {
+                PT_HIP(ctx, hipMalloc((void **)&ctx->d_cams[i], cam_bytes));
+                PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_cams[i], cam_bytes, hipHostMallocDefault));
+                PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_cams[i], hipEventDisableTiming));
+            }
+            if (ctx->cams_used[i]) PT_HIP(ctx, hipEventSynchronize(ctx->ev_cams[i]));   // its last reader, kCamRing uploads ago
+            std::memcpy(ctx->h_cams[i], ctx->camera_history.data(), cam_bytes);
+            PT_HIP(ctx, hipMemcpyAsync(ctx->d_cams[i], ctx->h_cams[i], cam_bytes, hipMemcpyHostToDevice, ctx->stream));
             ctx->cams_dirty = false;
         }
         if (mode == 6) {
@@ -751,10 +769,12 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
             if (s_rows && (rc = launch_path(ctx, prim, 0, s_hi + 1, ctx->W, ctx->H - s_hi - 1))) return rc;
         }
         StripeArgs sa;
-        sa.cams = ctx->d_cams; sa.t_primary = ctx->d_seeds; sa.divisions = p->divisions; sa.counter = p->counter; sa.mode = mode;
+        sa.cams = ctx->d_cams[ctx->cam_slot]; sa.t_primary = ctx->d_seeds; sa.divisions = p->divisions; sa.counter = p->counter; sa.mode = mode;
         const dim3 blk(kScreenBlockX, kScreenBlockY), grd((ctx->W + kScreenBlockX - 1) / kScreenBlockX, (ctx->H + kScreenBlockY - 1) / kScreenBlockY);
         hipLaunchKernelGGL(stripe_reproject_kernel, grd, blk, 0, ctx->stream, a, sa);
         PT_HIP(ctx, hipGetLastError());
+        PT_HIP(ctx, hipEventRecord(ctx->ev_cams[ctx->cam_slot], ctx->stream));
+        ctx->cams_used[ctx->cam_slot] = true;
         if (s_rows && !no_samples && (rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
         if (s_rows && p->depth != 1)   // SH:1108-1112, after every read of Result1 above
             PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)s_lo * ctx->W, pitch, ctx->result + (size_t)s_lo * ctx->W, pitch,
