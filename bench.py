@@ -200,6 +200,7 @@ def main():
             out["stereo_1080p"] = stereo_frame_time(pa, torch)
         if not args.no_stereo and world == 1:
             out["blob70k_1080p"] = secondary_scene_rate(pa, torch, sky)
+            out["ggx_1080p"] = secondary_scene_rate(pa, torch, sky, name=args.scene, ggx=True)
         if not args.no_reproj and world == 1:
             out["reproj_1080p"] = reproj_frame_time(pa, torch, scene, sky)
         if world == 1 and not args.no_cpu_baseline:
@@ -244,11 +245,15 @@ def stereo_frame_time(pa, torch, frames=30):
     return {"ms_per_frame": ms, "frames": frames, "config": "xr scene, 2 x 1920x1080, 1 spp, 4 bounces, mean accumulation, 1 GPU"}
 
 
-def secondary_scene_rate(pa, torch, sky, frames=5):
-    """Mrays/s on the ~70 k-triangle mesh scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU)."""
-    scene = pa.Scene("blob70k")
+def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False):
+    """Mrays/s on another scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU): the ~70 k-triangle
+    mesh, or (ggx) the bench scene with every mesh object given a GGX metal surface instead of the shader's
+    hard-coded Phong one (PtMaterial, an extension)."""
+    scene = pa.Scene(name)
     t = pa.PathTracer(torch.cuda.current_device())
     t.load_scene(scene, sky); t.resize(1920, 1080)
+    if ggx:
+        t.set_mesh_materials(pa.materials([((0.0, 0.0, 0.0), 0.8, (0.95, 0.64, 0.54), pa.PT_LOBE_GGX)] * len(scene.objects)))
     t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(0), spp=16, max_bounces=8)); t.stats()
     t0 = time.perf_counter()
     for k in range(frames):
@@ -258,7 +263,8 @@ def secondary_scene_rate(pa, torch, sky, frames=5):
     st = t.stats()
     t.close()
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
-            "config": f"blob70k ({scene.n_triangles} triangles + spheres + plane), 1920x1080, 8 bounces, 16 spp, 1 GPU"}
+            "config": f"{name} ({scene.n_triangles} triangles + spheres + plane{', GGX copper on every mesh' if ggx else ''}), "
+                      "1920x1080, 8 bounces, 16 spp, 1 GPU"}
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):

@@ -60,6 +60,23 @@ typedef struct PtMeshObject {
     int32_t indices_count;
 } PtMeshObject;
 
+/* Surface of a mesh object.  The shader hard-codes one for every triangle (albedo 0, specular .65,
+ * smoothness .99, emission 0: RayTracingShader.compute:250-253), which is what applies until
+ * pt_set_mesh_materials supplies others; the fields are the ones RayHit carries (:126-135).
+ * lobe picks the specular sampling: PT_LOBE_PHONG is the shader's (:345-353, modified Phong with
+ * alpha = 1000^(smoothness^2)); PT_LOBE_GGX is an extension with no counterpart in the reference:
+ * a GGX microfacet lobe of roughness (1 - smoothness)^2 with Smith shadowing and Schlick Fresnel
+ * (F0 = specular), sampled through its normal distribution.  The diffuse branch is the shader's. */
+enum { PT_LOBE_PHONG = 0, PT_LOBE_GGX = 1 };
+typedef struct PtMaterial {
+    float albedo[3];
+    float smoothness;
+    float specular[3];
+    int32_t lobe;
+    float emission[3];
+    float reserved;
+} PtMaterial;
+
 /* Accumulation of the fresh frame into the converged image. */
 enum {
     PT_ACCUM_NONE = 0,   /* Result only                                                            */
@@ -159,6 +176,10 @@ int pt_set_spheres(pt_context *ctx, const PtSphere *spheres, int count);
 int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects,
                   const float *vertices, int n_vertices,
                   const int32_t *indices, int n_indices);
+
+/* One PtMaterial per mesh object of the last pt_set_meshes, in the same order; count 0 goes back to
+ * the shader's hard-coded surface.  No counterpart in the reference (its MeshObject has no material). */
+int pt_set_mesh_materials(pt_context *ctx, const PtMaterial *materials, int count);
 
 /* Same geometry, new localToWorld matrices (what a transform change costs the
  * reference: a full re-upload, RayTracingMaster.cs:254-262,371-413).  On a scene

@@ -22,16 +22,18 @@ typedef struct Ray { f3 origin, direction, energy; } Ray;        /* SH:92-97 */
 
 typedef struct RayHit {                                          /* SH:126-135 */
     f3 position; float distance; f3 normal; f3 albedo; f3 specular; float smoothness; f3 emission;
+    int32_t lobe; /* PtMaterial.lobe; not in the shader (always its Phong lobe there) */
     int32_t id; /* not in the shader: -1 miss, 0 plane, 1+i sphere i, 1+nS+k triangle k */
 } RayHit;
 
-typedef struct Tri { f3 v0, v1, v2; } Tri;
+typedef struct Tri { f3 v0, v1, v2; int32_t object; } Tri;
 
 typedef struct ONode { float lo[3], hi[3]; int32_t left, right; int32_t first, count; } ONode;
 
 struct PtoPrepared {
     PtSphere *spheres; int32_t n_spheres;
     Tri *tris; int32_t n_tris;           /* world space, reference order */
+    PtMaterial *materials; int32_t n_materials;   /* per mesh object; none = SH:250-253 for every triangle */
     float *sky; int32_t sky_w, sky_h;
     int accel;
     ONode *nodes; int32_t n_nodes; int32_t *order; /* BVH over prim ids 1.. (spheres then tris) */
@@ -92,6 +94,7 @@ static void intersect_ground_plane(const Ray *ray, RayHit *best)
         best->albedo = pt_make3(0.5f, 0.5f, 0.5f);
         best->specular = pt_make3(0.03f, 0.03f, 0.03f);
         best->smoothness = 0.2f;
+        best->lobe = PT_LOBE_PHONG;
         best->emission = pt_make3(0, 0, 0);
         best->id = 0;
     }
@@ -115,6 +118,7 @@ static void intersect_sphere(const Ray *ray, RayHit *best, const PtSphere *s, in
         best->specular = pt_make3(s->specular[0], s->specular[1], s->specular[2]);
         best->smoothness = s->smoothness;
         best->emission = pt_make3(s->emission[0], s->emission[1], s->emission[2]);
+        best->lobe = PT_LOBE_PHONG;
         best->id = id;
     }
 }
@@ -141,7 +145,7 @@ static int intersect_triangle_mt97(const Ray *ray, f3 vert0, f3 vert1, f3 vert2,
 /* Body of the loop at SH:236-256 for one triangle already in world space (the
  * shader re-applies localToWorldMatrix per ray, SH:238-240; pto_prepare applies
  * the same pt_mul_point once, which yields the same bits). */
-static void intersect_tri(const Ray *ray, RayHit *best, const Tri *tr, int32_t id, int lexi)
+static void intersect_tri(const Ray *ray, RayHit *best, const Tri *tr, int32_t id, int lexi, const PtMaterial *materials)
 {
     float t, u, v;
     if (intersect_triangle_mt97(ray, tr->v0, tr->v1, tr->v2, &t, &u, &v)) {
@@ -149,10 +153,19 @@ static void intersect_tri(const Ray *ray, RayHit *best, const Tri *tr, int32_t i
             best->distance = t;
             best->position = pt_along3(ray->origin, t, ray->direction);
             best->normal = pt_normalize3(pt_cross3(pt_sub3(tr->v1, tr->v0), pt_sub3(tr->v2, tr->v0)));
-            best->albedo = pt_make3(0, 0, 0);
+            best->albedo = pt_make3(0, 0, 0);                       /* SH:250-253 */
             best->specular = pt_make3(0.65f, 0.65f, 0.65f);
             best->smoothness = 0.99f;
             best->emission = pt_make3(0, 0, 0);
+            best->lobe = PT_LOBE_PHONG;
+            if (materials) {                                        /* extension: the object's own surface */
+                const PtMaterial *m = &materials[tr->object];
+                best->albedo = pt_make3(m->albedo[0], m->albedo[1], m->albedo[2]);
+                best->specular = pt_make3(m->specular[0], m->specular[1], m->specular[2]);
+                best->smoothness = m->smoothness;
+                best->emission = pt_make3(m->emission[0], m->emission[1], m->emission[2]);
+                best->lobe = m->lobe;
+            }
             best->id = id;
         }
     }
@@ -191,7 +204,7 @@ static void trace_bvh(const PtoPrepared *p, const Ray *ray, RayHit *best, Counte
                 int32_t id = p->order[n->first + k];
                 cn->prims++;
                 if (id <= p->n_spheres) intersect_sphere(ray, best, &p->spheres[id - 1], id, 1);
-                else intersect_tri(ray, best, &p->tris[id - 1 - p->n_spheres], id, 1);
+                else intersect_tri(ray, best, &p->tris[id - 1 - p->n_spheres], id, 1, p->materials);
             }
         } else {
             stack[sp++] = n->left; stack[sp++] = n->right;
@@ -210,7 +223,7 @@ static RayHit trace(const PtoPrepared *p, const Ray *ray, Counters *cn)
         intersect_sphere(ray, &best, &p->spheres[i], 1 + i, 0);
     /* mesh objects in order, triangles in order: p->tris is that flattened order */
     for (int32_t k = 0; k < p->n_tris; k++)
-        intersect_tri(ray, &best, &p->tris[k], 1 + p->n_spheres + k, 0);
+        intersect_tri(ray, &best, &p->tris[k], 1 + p->n_spheres + k, 0, p->materials);
     cn->prims += (uint64_t)p->n_spheres + (uint64_t)p->n_tris;
     return best;
 }
@@ -240,12 +253,19 @@ static void get_tangent_space(f3 normal, f3 *tangent, f3 *binormal)
 }
 
 /* SH:304-314 */
+static f3 tangent_to_world(f3 normal, f3 ts);
+
 static f3 sample_hemisphere(RngState *rs, f3 normal, float alpha)
 {
     float cosTheta = pt_pow(rng(rs), 1.0f / (alpha + 1.0f));
     float sinTheta = pt_sqrt(1.0f - cosTheta * cosTheta);
     float phi = 2 * PT_PI * rng(rs);
     f3 ts = pt_make3(pt_cos(phi) * sinTheta, pt_sin(phi) * sinTheta, cosTheta);
+    return tangent_to_world(normal, ts);
+}
+
+static f3 tangent_to_world(f3 normal, f3 ts)   /* SH:310-313 */
+{
     f3 tangent, binormal;
     get_tangent_space(normal, &tangent, &binormal);
     /* mul(tangentSpaceDir, float3x3(tangent, binormal, normal)): row vector times matrix */
@@ -257,6 +277,32 @@ static f3 sample_hemisphere(RngState *rs, f3 normal, float alpha)
 }
 
 static float smoothness_to_phong_alpha(float s) { return pt_pow(1000.0f, s * s); } /* SH:319-322 */
+
+/* PT_LOBE_GGX (extension, no counterpart in the shader): sample the GGX normal distribution of roughness
+ * a = max((1-smoothness)^2, 1e-3) - cos(theta_h) first, phi second, like SampleHemisphere -, mirror the ray
+ * about the half-vector, return f*cos/pdf = F*G*(v.h)/((n.v)(n.h)) per channel (Schlick F with F0 = specular,
+ * Smith separable G) or zero when the sample leaves the upper hemisphere. */
+static f3 sample_ggx(RngState *rs, f3 normal, f3 specular, float smoothness, f3 *dir)
+{
+    float rough = 1.0f - smoothness;
+    float a = pt_max(rough * rough, 1e-3f), a2 = a * a;
+    float u1 = rng(rs);
+    float cos2 = (1.0f - u1) / (1.0f + (a2 - 1.0f) * u1);
+    float cosT = pt_sqrt(cos2), sinT = pt_sqrt(1.0f - cos2);
+    float phi = 2 * PT_PI * rng(rs);
+    f3 h = tangent_to_world(normal, pt_make3(pt_cos(phi) * sinT, pt_sin(phi) * sinT, cosT));
+    f3 v = pt_make3(-dir->x, -dir->y, -dir->z);
+    float vh = pt_dot3(v, h);
+    *dir = pt_reflect3(*dir, h);
+    float nl = pt_dot3(normal, *dir), nv = pt_dot3(normal, v), nh = pt_dot3(normal, h);
+    if (!(nl > 0.0f && nv > 0.0f && vh > 0.0f && nh > 0.0f)) return pt_make3(0, 0, 0);
+    float m = 1.0f - vh, m2 = m * m, m5 = m2 * m2 * m;
+    float g1v = 2.0f * nv / (nv + pt_sqrt(a2 + (1.0f - a2) * nv * nv));
+    float g1l = 2.0f * nl / (nl + pt_sqrt(a2 + (1.0f - a2) * nl * nl));
+    float w = g1v * g1l * vh / (nv * nh);
+    return pt_make3((specular.x + (1.0f - specular.x) * m5) * w, (specular.y + (1.0f - specular.y) * m5) * w,
+                    (specular.z + (1.0f - specular.z) * m5) * w);
+}
 
 /* _SkyboxTexture.SampleLevel(sampler, uv, 0): bilinear, Repeat wrap on both
  * axes, texel centres at (i+0.5)/N, weights in fp32; lerp(a,b,t) = a + t*(b-a). */
@@ -300,7 +346,14 @@ static f3 shade(const PtoPrepared *p, RngState *rs, Ray *ray, RayHit hit)
         float specChance = energy(hit.specular);
         float diffChance = energy(hit.albedo);
         float roulette = rng(rs);
-        if (roulette < specChance) {
+        if (roulette < specChance && hit.lobe == PT_LOBE_GGX) {
+            ray->origin = pt_along3(hit.position, 0.001f, hit.normal);
+            float k = (1.0f / specChance);
+            f3 w = sample_ggx(rs, hit.normal, hit.specular, hit.smoothness, &ray->direction);
+            ray->energy.x *= k * w.x;
+            ray->energy.y *= k * w.y;
+            ray->energy.z *= k * w.z;
+        } else if (roulette < specChance) {
             ray->origin = pt_along3(hit.position, 0.001f, hit.normal); /* position + normal*0.001 */
             float alpha = smoothness_to_phong_alpha(hit.smoothness);
             ray->direction = sample_hemisphere(rs, pt_reflect3(ray->direction, hit.normal), alpha);
@@ -828,10 +881,16 @@ PtoPrepared *pto_prepare(const PtoScene *sc, int accel)
             p->tris[k].v0 = pt_mul_point(mo->local_to_world, pt_make3(a[0], a[1], a[2])); /* SH:238-240 */
             p->tris[k].v1 = pt_mul_point(mo->local_to_world, pt_make3(b[0], b[1], b[2]));
             p->tris[k].v2 = pt_mul_point(mo->local_to_world, pt_make3(c[0], c[1], c[2]));
+            p->tris[k].object = o;
             k++;
         }
     }
     p->n_tris = (int32_t)k;
+    if (sc->materials && sc->n_materials == sc->n_objects && sc->n_objects > 0) {
+        p->materials = (PtMaterial *)malloc(sizeof(PtMaterial) * (size_t)sc->n_materials);
+        memcpy(p->materials, sc->materials, sizeof(PtMaterial) * (size_t)sc->n_materials);
+        p->n_materials = sc->n_materials;
+    }
     if (sc->sky && sc->sky_w > 0 && sc->sky_h > 0) {
         size_t n = (size_t)sc->sky_w * sc->sky_h * 4;
         p->sky = (float *)malloc(n * sizeof(float));
@@ -854,7 +913,7 @@ PtoPrepared *pto_prepare(const PtoScene *sc, int accel)
 void pto_release(PtoPrepared *p)
 {
     if (!p) return;
-    free(p->spheres); free(p->tris); free(p->sky); free(p->nodes); free(p->order); free(p);
+    free(p->spheres); free(p->tris); free(p->sky); free(p->nodes); free(p->order); free(p->materials); free(p);
 }
 
 /* ------------------------------------------------------ pieces for KATs */

@@ -32,6 +32,7 @@ typedef struct PtoScene {
     const float *vertices;        int32_t n_vertices;
     const int32_t *indices;       int32_t n_indices;
     const float *sky;             int32_t sky_w, sky_h;   /* RGBA32F; NULL = black sky */
+    const PtMaterial *materials;  int32_t n_materials;    /* one per object, or 0 = the shader's hard-coded surface */
 } PtoScene;
 
 typedef struct PtoStats {

@@ -22,7 +22,8 @@ LIB_PATH = os.path.join(_HERE, "_build", "libptoracle.so")
 class PtoScene(C.Structure):
     _fields_ = [("spheres", C.c_void_p), ("n_spheres", C.c_int32), ("objects", C.c_void_p), ("n_objects", C.c_int32),
                 ("vertices", C.c_void_p), ("n_vertices", C.c_int32), ("indices", C.c_void_p), ("n_indices", C.c_int32),
-                ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32)]
+                ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32),
+                ("materials", C.c_void_p), ("n_materials", C.c_int32)]
 
 
 class PtoStats(C.Structure):
@@ -68,7 +69,7 @@ class Oracle:
     """A prepared scene. accel=False is the reference's exhaustive loop; accel=True
     uses the oracle's own BVH (same winner, checked against accel=False in tests)."""
 
-    def __init__(self, spheres, objects, vertices, indices, sky=None, accel=False):
+    def __init__(self, spheres, objects, vertices, indices, sky=None, accel=False, materials=None):
         self._keep = [np.ascontiguousarray(spheres, np.float32).reshape(-1, 14), np.ascontiguousarray(objects),
                       np.ascontiguousarray(vertices, np.float32).reshape(-1, 3), np.ascontiguousarray(indices, np.int32)]
         s, o, v, i = self._keep
@@ -81,13 +82,18 @@ class Oracle:
             k = np.ascontiguousarray(sky, np.float32)
             self._keep.append(k)
             sc.sky = k.ctypes.data; sc.sky_h, sc.sky_w = k.shape[:2]
+        if materials is not None and len(materials):
+            m = np.ascontiguousarray(materials)
+            assert m.dtype.itemsize == 48 and len(m) == len(o)
+            self._keep.append(m)
+            sc.materials = m.ctypes.data; sc.n_materials = len(m)
         self._p = lib().pto_prepare(C.byref(sc), int(bool(accel)))
         if not self._p:
             raise MemoryError("pto_prepare failed")
 
     @classmethod
-    def from_scene(cls, scene, sky=None, accel=False):
-        return cls(scene.spheres, scene.objects, scene.vertices, scene.indices, sky, accel)
+    def from_scene(cls, scene, sky=None, accel=False, materials=None):
+        return cls(scene.spheres, scene.objects, scene.vertices, scene.indices, sky, accel, materials)
 
     def __del__(self):
         try:

@@ -35,13 +35,20 @@ class PtCameraHistory(C.Structure):
                 ("world_to_camera", C.c_float * 16), ("camera_projection", C.c_float * 16)]
 
 
+class PtMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("smoothness", C.c_float), ("specular", C.c_float * 3), ("lobe", C.c_int32),
+                ("emission", C.c_float * 3), ("reserved", C.c_float)]
+
+
 class PtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
                 ("paths", C.c_uint64), ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32),
                 ("bvh_prims", C.c_int32), ("bvh_depth", C.c_int32), ("bvh_build_ms", C.c_float)]
 
 
-assert C.sizeof(PtSphere) == 56 and C.sizeof(PtMeshObject) == 72
+assert C.sizeof(PtSphere) == 56 and C.sizeof(PtMeshObject) == 72 and C.sizeof(PtMaterial) == 48
+
+PT_LOBE_PHONG, PT_LOBE_GGX = 0, 1
 
 PT_ACCUM_NONE, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_ACCUM_ADDMAT = 0, 1, 2, 3
 PT_TARGET_RESULT, PT_TARGET_CONVERGED, PT_TARGET_HIT_IDS, PT_TARGET_DENOISED = 0, 1, 2, 3
@@ -58,6 +65,7 @@ PTRACE_SYMBOLS = {
     "pt_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
     "pt_set_spheres": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pt_set_meshes": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "pt_set_mesh_materials": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pt_update_transforms": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pt_set_sky": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "pt_set_camera_history": (C.c_int, [_ctx, C.c_void_p, C.c_int]),

@@ -22,11 +22,13 @@ struct SceneDev {
     const float4 *prims;       // 3 x float4 per primitive record, BVH order
     const float4 *sphere_mat;  // 4 x float4 per sphere: (pos,r) (albedo,smoothness) (specular,0) (emission,0)
     const float4 *sky;         // RGBA32F texels, row 0 at v = 0
+    const float4 *mesh_mat;    // 3 x float4 per mesh object: (albedo, smoothness) (specular, bits(lobe)) (emission, 0);
+                               // NULL = the shader's hard-coded surface for every triangle (SH:250-253)
     int32_t sky_w, sky_h;
     int32_t n_nodes, n_prims, n_spheres;
 };
 
-// Primitive record (48 B): a = (v0.xyz, bits(id)), b = (e1.xyz, bits(kind)), c = (e2.xyz, 0)
+// Primitive record (48 B): a = (v0.xyz, bits(id)), b = (e1.xyz, bits(kind)), c = (e2.xyz, bits(mesh object index))
 // with e1 = v1 - v0, e2 = v2 - v0 in world space (kind 0), or for a sphere
 // a = (centre.xyz, bits(id)), b = (radius, 0, 0, bits(1)).
 // id: 1 + i for sphere i, 1 + n_spheres + k for triangle k in the reference's
@@ -325,13 +327,21 @@ __device__ __forceinline__ float rng_next(Rng &r)  // SH:50-55
     return result;
 }
 
-// SH:291-314
+// GetTangentSpace + mul(tangentSpaceDir, basis), SH:291-302, SH:313
+__device__ __forceinline__ f3 tangent_to_world(f3 normal, f3 ts);
+
+// SH:304-314
 __device__ __forceinline__ f3 sample_hemisphere(Rng &rs, f3 normal, float alpha)
 {
     float cosTheta = pt_pow(rng_next(rs), 1.0f / (alpha + 1.0f));
     float sinTheta = pt_sqrt(1.0f - cosTheta * cosTheta);
     float phi = 2 * PT_PI * rng_next(rs);
     f3 ts = pt_make3(pt_cos(phi) * sinTheta, pt_sin(phi) * sinTheta, cosTheta);
+    return tangent_to_world(normal, ts);
+}
+
+__device__ __forceinline__ f3 tangent_to_world(f3 normal, f3 ts)
+{
     f3 helper = pt_make3(1, 0, 0);
     if (pt_abs(normal.x) > 0.99f) helper = pt_make3(0, 0, 1);
     f3 tangent = pt_normalize3(pt_cross3(normal, helper));
@@ -364,14 +374,45 @@ __device__ __forceinline__ f3 sky_sample(const SceneDev &sc, f3 dir)
     return pt_scale3(c, 2.0f);
 }
 
+// The GGX extension of the specular branch (PtMaterial.lobe == PT_LOBE_GGX; no counterpart in the shader).
+// Draws cos(theta_h) first and phi second, as SampleHemisphere does, from the GGX normal distribution of
+// roughness a = max((1 - smoothness)^2, 1e-3):  cos^2 = (1 - u1) / (1 + (a^2 - 1) u1);  the new direction is the
+// mirror image of the incoming one about that half-vector.  Returns the throughput f * cos / pdf =
+// F * G * (v.h) / ((n.v)(n.h)) per channel with Schlick's F (F0 = specular) and Smith's separable G, or zero
+// when the sample leaves the upper hemisphere.
+__device__ __forceinline__ f3 sample_ggx(Rng &rs, f3 normal, f3 specular, float smoothness, f3 &d)
+{
+    const float rough = 1.0f - smoothness;
+    const float a = pt_max(rough * rough, 1e-3f), a2 = a * a;
+    const float u1 = rng_next(rs);
+    const float cos2 = (1.0f - u1) / (1.0f + (a2 - 1.0f) * u1);
+    const float cosT = pt_sqrt(cos2), sinT = pt_sqrt(1.0f - cos2);
+    const float phi = 2 * PT_PI * rng_next(rs);
+    const f3 h = tangent_to_world(normal, pt_make3(pt_cos(phi) * sinT, pt_sin(phi) * sinT, cosT));
+    const f3 v = pt_make3(-d.x, -d.y, -d.z);
+    const float vh = pt_dot3(v, h);
+    d = pt_reflect3(d, h);
+    const float nl = pt_dot3(normal, d), nv = pt_dot3(normal, v), nh = pt_dot3(normal, h);
+    if (!(nl > 0.0f && nv > 0.0f && vh > 0.0f && nh > 0.0f)) return pt_make3(0, 0, 0);
+    const float m = 1.0f - vh, m2 = m * m, m5 = m2 * m2 * m;
+    const float g1v = 2.0f * nv / (nv + pt_sqrt(a2 + (1.0f - a2) * nv * nv));
+    const float g1l = 2.0f * nl / (nl + pt_sqrt(a2 + (1.0f - a2) * nl * nl));
+    const float w = g1v * g1l * vh / (nv * nh);
+    return pt_make3((specular.x + (1.0f - specular.x) * m5) * w, (specular.y + (1.0f - specular.y) * m5) * w,
+                    (specular.z + (1.0f - specular.z) * m5) * w);
+}
+
 // Shade (SH:334-373) for the hit (t, id, rec) together with the accumulation of SH:866/870:
 // result += energy_before * Shade() / spp.  Updates origin/direction/energy in place.
 // `hit_pos` receives bestHit.position ((0,0,0) on a miss, SH:140).  Values are consumed as early
 // as the arithmetic allows (emission right after the material fetch, the material folded into one
 // weight before the hemisphere sampling) to keep few registers live across the sampling code.
+// MAT: mesh objects carry their own PtMaterial (SceneDev::mesh_mat), possibly with the GGX lobe.
+template <bool MAT = false>
 __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f3 &energy, f3 &result, float fspp,
                                       float t, int32_t id, uint32_t rec, f3 &hit_pos)
 {
+    int lobe = PT_LOBE_PHONG;
     if (!(t < PT_INF)) {
         hit_pos = pt_make3(0, 0, 0);
         f3 sky = sky_sample(sc, d);
@@ -403,10 +444,18 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
     } else {                                        // SH:249-253
         float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
         normal = pt_normalize3(pt_cross3(xyz(b), xyz(c)));
-        albedo = pt_make3(0, 0, 0);
-        specular = pt_make3(0.65f, 0.65f, 0.65f);
-        smoothness = 0.99f;
-        result.x += energy.x * 0.0f / fspp; result.y += energy.y * 0.0f / fspp; result.z += energy.z * 0.0f / fspp;
+        if (MAT && sc.mesh_mat) {
+            const float4 *m = sc.mesh_mat + (size_t)as_i(c.w) * 3;
+            const float4 m0 = m[0], m1 = m[1], m2 = m[2];
+            albedo = xyz(m0); smoothness = m0.w;
+            specular = xyz(m1); lobe = as_i(m1.w);
+            result.x += energy.x * m2.x / fspp; result.y += energy.y * m2.y / fspp; result.z += energy.z * m2.z / fspp;
+        } else {
+            albedo = pt_make3(0, 0, 0);
+            specular = pt_make3(0.65f, 0.65f, 0.65f);
+            smoothness = 0.99f;
+            result.x += energy.x * 0.0f / fspp; result.y += energy.y * 0.0f / fspp; result.z += energy.z * 0.0f / fspp;
+        }
     }
     albedo = pt_make3(pt_min(1.0f - specular.x, albedo.x), pt_min(1.0f - specular.y, albedo.y),
                       pt_min(1.0f - specular.z, albedo.z));
@@ -418,7 +467,14 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
     // merged here so that a wave runs that code once, each lane with its own axis and alpha.
     const bool spec = roulette < specChance;
     const bool diff = !spec && diffChance > 0 && roulette < specChance + diffChance;
-    if (spec || diff) {
+    if (MAT && spec && lobe == PT_LOBE_GGX) {
+        const float k = 1.0f / specChance;
+        o = pt_along3(position, 0.001f, normal);
+        const f3 w = sample_ggx(rs, normal, specular, smoothness, d);
+        energy.x *= k * w.x;
+        energy.y *= k * w.y;
+        energy.z *= k * w.z;
+    } else if (spec || diff) {
         // (1/chance) * colour, the left factor of SH:352 / SH:359
         const float k = 1.0f / (spec ? specChance : diffChance);
         const f3 weight = spec ? pt_make3(k * specular.x, k * specular.y, k * specular.z)
@@ -638,8 +694,8 @@ __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && n
 // That keeps the register count of the traversal phases, and with it the kernel's occupancy, down.
 //   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, t of the primary hit)
 //   ls2 = (pixel x | y << 16, sample, bounce, primary id)   ls3 = (rays, nodes, prims, paths) counters
-template <int WIDE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_kernel(const RenderArgs a)
+template <int WIDE, bool MAT>
+__device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 {
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
     __shared__ float lds_save[9 * kBlock];   // traversal-only registers parked here during a shade phase
@@ -712,7 +768,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                     float t_primary = s1.w;
                     Rng rs = {s0.w, pixel_dot(pix_x, pix_y)};
                     f3 hit_pos;
-                    shade(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
+                    shade<MAT>(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
                     bool path_done;
                     if (bounce == 0) {
                         primary_id = idbest;
@@ -851,6 +907,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 #undef ls1
 #undef ls2
 #undef ls3
+
+template <int WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_kernel(const RenderArgs a)
+{
+    path_sched_body<WIDE, false>(a);
+}
+
+// The same kernel for scenes whose mesh objects carry materials (pt_set_mesh_materials); kept apart so that
+// the extra shading code cannot cost the default kernel registers.
+template <int WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_mat_kernel(const RenderArgs a)
+{
+    path_sched_body<WIDE, true>(a);
+}
 
 template <int WIDE>
 __global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uint32_t *stack_overflow, const float *od, int n,

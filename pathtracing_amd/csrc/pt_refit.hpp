@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
         const float idf = a.prims[(size_t)slot * 3].w;
         a.prims[(size_t)slot * 3 + 0] = make_float4(v0.x, v0.y, v0.z, idf);
         a.prims[(size_t)slot * 3 + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
-        a.prims[(size_t)slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        a.prims[(size_t)slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, __int_as_float(src.x));   // the mesh object's index
         lo[0] = fminf(v0.x, fminf(v1.x, v2.x)); hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
         lo[1] = fminf(v0.y, fminf(v1.y, v2.y)); hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
         lo[2] = fminf(v0.z, fminf(v1.z, v2.z)); hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));

@@ -33,6 +33,8 @@ struct pt_context {
     std::vector<float> vertices;
     std::vector<int32_t> indices;
     bool scene_dirty = true;
+    std::vector<PtMaterial> materials;             // pt_set_mesh_materials; empty = the shader's hard-coded surface
+    float4 *d_mesh_mat = nullptr;
     std::vector<PtCameraHistory> camera_history = std::vector<PtCameraHistory>(PT_MAX_CAMERA_HISTORY);   // the four *Old arrays; zero-initialised
     // device copies for the partial-frame modes: a small ring, so that an upload never waits for the frame
     // that still reads the previous copy (pinned staging buffer + device buffer + "last reader done" event each)
@@ -149,12 +151,15 @@ int rebuild_scene(pt_context *ctx)
     const int nS = (int)ctx->spheres.size();
     struct Tri { pt_f3 v0, v1, v2; };
     std::vector<Tri> tris;
+    std::vector<int32_t> tri_object;
     size_t nt = 0;
     for (const PtMeshObject &mo : ctx->objects) nt += (size_t)std::max(0, mo.indices_count) / 3;
-    tris.reserve(nt);
-    for (const PtMeshObject &mo : ctx->objects) {
+    tris.reserve(nt); tri_object.reserve(nt);
+    for (size_t oi = 0; oi < ctx->objects.size(); oi++) {
+        const PtMeshObject &mo = ctx->objects[oi];
         const int32_t end = mo.indices_offset + mo.indices_count;
         for (int32_t i = mo.indices_offset; i + 2 < end; i += 3) {
+            tri_object.push_back((int32_t)oi);
             const float *a = &ctx->vertices[3 * (size_t)ctx->indices[i]];
             const float *b = &ctx->vertices[3 * (size_t)ctx->indices[i + 1]];
             const float *c = &ctx->vertices[3 * (size_t)ctx->indices[i + 2]];
@@ -226,7 +231,8 @@ int rebuild_scene(pt_context *ctx)
             pt_f3 e1 = pt_sub3(t.v1, t.v0), e2 = pt_sub3(t.v2, t.v0);
             recs[slot * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, idf);
             recs[slot * 3 + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
-            recs[slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+            float objf; std::memcpy(&objf, &tri_object[prim - nS], 4);
+            recs[slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, objf);
         }
     }
     std::vector<float4> smat((size_t)nS * 4);
@@ -308,6 +314,7 @@ SceneDev scene_dev(const pt_context *ctx)
 {
     SceneDev sc;
     sc.nodes = ctx->d_nodes; sc.nodes4 = ctx->d_nodes4; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
+    sc.mesh_mat = ctx->d_mesh_mat;
     sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
     sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres;
     return sc;
@@ -492,7 +499,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
-    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes);
+    free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
     for (int i = 0; i < pt_context::kCamRing; i++) {
         free_dev(ctx->d_cams[i]);
         if (ctx->h_cams[i]) (void)hipHostFree(ctx->h_cams[i]);
@@ -537,7 +544,36 @@ int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, c
     ctx->vertices.assign(vertices, vertices + (size_t)n_vertices * 3);
     ctx->indices.assign(indices, indices + n_indices);
     ctx->scene_dirty = true;
+    if (!ctx->materials.empty()) {            // materials belong to the object list they were given for
+        DeviceGuard g(ctx->device);
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->materials.clear();
+        free_dev(ctx->d_mesh_mat);
+    }
     return PT_OK;
+}
+
+int pt_set_mesh_materials(pt_context *ctx, const PtMaterial *materials, int count)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (count < 0 || (count > 0 && !materials)) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh_materials: bad arguments");
+    if (count != 0 && count != (int)ctx->objects.size())
+        return fail(ctx, PT_ERR_INVALID, "pt_set_mesh_materials: one material per mesh object of pt_set_meshes (or none)");
+    for (int i = 0; i < count; i++)
+        if (materials[i].lobe != PT_LOBE_PHONG && materials[i].lobe != PT_LOBE_GGX)
+            return fail(ctx, PT_ERR_INVALID, "pt_set_mesh_materials: unknown lobe");
+    DeviceGuard g(ctx->device);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->materials.assign(materials, materials + count);
+    std::vector<float4> table((size_t)count * 3);
+    for (int i = 0; i < count; i++) {
+        const PtMaterial &m = materials[i];
+        float lobef; std::memcpy(&lobef, &m.lobe, 4);
+        table[(size_t)i * 3 + 0] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.smoothness);
+        table[(size_t)i * 3 + 1] = make_float4(m.specular[0], m.specular[1], m.specular[2], lobef);
+        table[(size_t)i * 3 + 2] = make_float4(m.emission[0], m.emission[1], m.emission[2], 0.0f);
+    }
+    return upload(ctx, ctx->d_mesh_mat, table.data(), table.size() * sizeof(float4));
 }
 
 int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_objects)
@@ -648,7 +684,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     a.tiles_x = (tw + 7) / 8;
     const int tiles_y = (th + 7) / 8;
     a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
-    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1) return render_wavefront(ctx, a);
+    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !ctx->d_mesh_mat) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->sched_blocks_per_cu);
@@ -656,8 +692,13 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     a.stack_overflow = ctx->d_stack_ovf;
     a.lane_state = ctx->d_lane_state;
     a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
-    if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    if (ctx->d_mesh_mat) {
+        if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(path_sched_mat_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    } else {
+        if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    }
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
 }

@@ -80,6 +80,20 @@ def camera_matrices(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1, z_fa
     return c2w, ip
 
 
+MATERIAL_DTYPE = np.dtype([("albedo", np.float32, 3), ("smoothness", np.float32), ("specular", np.float32, 3),
+                           ("lobe", np.int32), ("emission", np.float32, 3), ("reserved", np.float32)])
+
+
+def materials(entries):
+    """PtMaterial array from (albedo, smoothness, specular, lobe[, emission]) tuples, one per mesh object."""
+    m = np.zeros(len(entries), MATERIAL_DTYPE)
+    for i, e in enumerate(entries):
+        m[i]["albedo"] = e[0]; m[i]["smoothness"] = e[1]; m[i]["specular"] = e[2]; m[i]["lobe"] = e[3]
+        if len(e) > 4:
+            m[i]["emission"] = e[4]
+    return m
+
+
 def camera_history_entry(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1, z_far=100.0):
     """One PtCameraHistory (cameraToWorld, inverse projection, worldToCamera, projection) for a look-at camera."""
     e = np.asarray(eye, np.float32); t = np.asarray(target, np.float32); u = np.asarray(up, np.float32)

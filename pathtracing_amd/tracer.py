@@ -60,6 +60,14 @@ class PathTracer:
                                             v.ctypes.data if len(v) else None, len(v),
                                             i.ctypes.data if len(i) else None, len(i)), "pt_set_meshes")
 
+    def set_mesh_materials(self, materials):
+        """materials: structured array of 48-byte PtMaterial records (scenes.materials), one per mesh object; None or
+        empty goes back to the shader's hard-coded surface."""
+        m = None if materials is None else np.ascontiguousarray(materials)
+        n = 0 if m is None else len(m)
+        assert n == 0 or m.dtype.itemsize == 48
+        self._check(self._lib.pt_set_mesh_materials(self._ctx, m.ctypes.data if n else None, n), "pt_set_mesh_materials")
+
     def update_transforms(self, objects):
         o = np.ascontiguousarray(objects)
         self._check(self._lib.pt_update_transforms(self._ctx, o.ctypes.data if len(o) else None, len(o)), "pt_update_transforms")

@@ -617,3 +617,45 @@ def test_stripe_mode_errors(tracer):
                dict(divisions=4, counter=1, tile=(0, 0, 20, 10)), dict(divisions=4, counter=1, accumulate=pa.PT_ACCUM_MEAN)):
         with pytest.raises(pa.PtraceError):
             tracer.render(pa.make_params(s, W, H, render_mode=5, **kw))
+
+
+# ------------------------------------------- per-mesh materials and the GGX lobe (extensions)
+
+def test_mesh_materials_and_ggx_match_oracle(tracer, sky_small):
+    """Three instances of one mesh with different surfaces - a GGX metal, a diffuse emitter, the shader's own
+    constants given explicitly - render bit-identically on both sides; dropping the materials restores the
+    hard-coded surface; a refit keeps every triangle's material."""
+    f = pa.Scene("fixture")
+    n_idx = len(f.indices)
+    objs = np.zeros(3, dtype=f.objects.dtype)
+    for k in range(3):
+        objs[k] = (_rot_y(15.0 * k, (-3.0 + 3.0 * k, 0.0, 1.5 * k)), 0, n_idx)
+    mats = pa.materials([((0.0, 0.0, 0.0), 0.8, (0.95, 0.64, 0.54), pa.PT_LOBE_GGX),
+                         ((0.7, 0.2, 0.1), 0.3, (0.04, 0.04, 0.04), pa.PT_LOBE_PHONG, (0.2, 0.2, 0.6)),
+                         ((0.0, 0.0, 0.0), 0.99, (0.65, 0.65, 0.65), pa.PT_LOBE_PHONG)])
+    tracer.set_spheres(f.spheres); tracer.set_meshes(objs, f.vertices, f.indices); tracer.set_sky(sky_small)
+    tracer.set_mesh_materials(mats)
+    W, H = 96, 54
+    tracer.resize(W, H)
+    p = pa.make_params(f, W, H, spp=4, max_bounces=6, seed=0.7, eye=(0, 5, -12), target=(0, 1, 2), fov=60)
+    tracer.stats(); tracer.render(p)
+    g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+    c, cid, cst = po.Oracle(f.spheres, objs, f.vertices, f.indices, sky=sky_small, materials=mats).render(p, W, H, threads=4)
+    assert (gid == cid).all() and st["rays"] == cst["rays"]
+    _assert_same_image(g, c, "materials")
+    plain = po.Oracle(f.spheres, objs, f.vertices, f.indices, sky=sky_small).render(p, W, H, threads=4)[0]
+    assert not (plain == c).all()
+    # refit: the records are rewritten on the device, each with its object's index
+    moved = objs.copy(); moved["m"][0] = _rot_y(40.0, (-3.5, 0.3, 0.5))
+    tracer.update_transforms(moved); tracer.render(p)
+    c2 = po.Oracle(f.spheres, moved, f.vertices, f.indices, sky=sky_small, materials=mats).render(p, W, H, threads=4)[0]
+    _assert_same_image(tracer.read_result(), c2, "materials after refit")
+    # back to the shader's surface
+    tracer.set_mesh_materials(None); tracer.render(p)
+    c3 = po.Oracle(f.spheres, moved, f.vertices, f.indices, sky=sky_small).render(p, W, H, threads=4)[0]
+    _assert_same_image(tracer.read_result(), c3, "materials removed")
+    with pytest.raises(pa.PtraceError):
+        tracer.set_mesh_materials(mats[:2])
+    bad = mats.copy(); bad["lobe"][0] = 7
+    with pytest.raises(pa.PtraceError, match="lobe"):
+        tracer.set_mesh_materials(bad)

@@ -532,3 +532,59 @@ def test_stripe_modes_properties(mode):
     interior = np.zeros((H, W), bool); interior[2:-2, 2:-2] = True
     close = np.abs(last[..., 3] - plain[..., 3]) < 0.05 * np.maximum(plain[..., 3], 1e-3)
     assert close[interior & (ids >= 0)].mean() > 0.8
+
+
+# ------------------------------------------- per-mesh materials and the GGX lobe (extensions)
+
+def _one_quad_scene(material):
+    """A large upward-facing quad at y = 1 (two triangles, one object) under a constant sky."""
+    v = np.array([[-50, 1, -50], [50, 1, -50], [50, 1, 50], [-50, 1, 50]], np.float32)
+    idx = np.array([0, 2, 1, 0, 3, 2], np.int32)            # counter-clockwise seen from above
+    objs = np.zeros(1, dtype=np.dtype([("m", np.float32, 16), ("offset", np.int32), ("count", np.int32)]))
+    objs[0] = (np.eye(4, dtype=np.float32).reshape(16), 0, 6)
+    return (np.zeros((0, 14), np.float32), objs, v, idx), pa.materials([material])
+
+
+def test_hard_coded_material_equals_its_explicit_form():
+    """Supplying the shader's own constants (SH:250-253) as a PtMaterial changes nothing."""
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    W, H = 32, 18
+    p = pa.make_params(s, W, H, spp=2, max_bounces=4)
+    a = po.Oracle.from_scene(s, sky).render(p, W, H)[0]
+    m = pa.materials([((0, 0, 0), 0.99, (0.65, 0.65, 0.65), pa.PT_LOBE_PHONG)] * len(s.objects))
+    b = po.Oracle.from_scene(s, sky, materials=m).render(p, W, H)[0]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_material_emission_and_albedo_reach_the_image():
+    sky = np.zeros((4, 8, 4), np.float32)
+    scene, m = _one_quad_scene(((0, 0, 0), 0.5, (0, 0, 0), pa.PT_LOBE_PHONG, (0.5, 1.0, 2.0)))
+    s = pa.Scene("fixture")
+    p = pa.make_params(s, 16, 8, spp=1, max_bounces=2, eye=(0, 5, 0), target=(0, 0, 0.01))
+    img, ids, _ = po.Oracle(*scene, sky=sky, materials=m).render(p, 16, 8)
+    assert (ids == 1).all() or (ids >= 1).all()
+    assert np.allclose(img[..., :3], (0.5, 1.0, 2.0))             # black, non-reflecting emitter: the emission alone
+
+
+def test_ggx_lobe_properties():
+    """White furnace: under a constant sky of radiance 1 a GGX surface never returns more than it receives
+    (the estimator F*G*(v.h)/((n.v)(n.h)) <= 1/specChance per sample has mean <= 1), a smooth one
+    returns nearly everything near normal incidence, and a rough one visibly less (no multiple scattering)."""
+    sky = np.full((4, 8, 4), 0.5, np.float32)                     # SkyboxSample doubles it (SH:331)
+    s = pa.Scene("fixture")
+    W, H = 24, 12
+    p = pa.make_params(s, W, H, spp=64, max_bounces=2, eye=(0, 6, 0), target=(0, 0, 0.01), fov=40)
+    means = {}
+    for smooth in (0.999, 0.7, 0.2):
+        scene, m = _one_quad_scene(((0, 0, 0), smooth, (1, 1, 1), pa.PT_LOBE_GGX))
+        img, ids, _ = po.Oracle(*scene, sky=sky, materials=m).render(p, W, H, threads=4)
+        assert (ids >= 1).all()
+        assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
+        means[smooth] = float(img[..., :3].mean())
+    assert 0.97 < means[0.999] <= 1.0 + 1e-3
+    assert means[0.2] < means[0.7] <= means[0.999] + 1e-3
+    assert means[0.2] > 0.3
+    # the Phong lobe of the shader on the same surface, for scale
+    scene, m = _one_quad_scene(((0, 0, 0), 0.999, (1, 1, 1), pa.PT_LOBE_PHONG))
+    ph = po.Oracle(*scene, sky=sky, materials=m).render(p, W, H, threads=4)[0]
+    assert abs(float(ph[..., :3].mean()) - means[0.999]) < 0.15   # the Phong lobe loses what it samples below the surface
