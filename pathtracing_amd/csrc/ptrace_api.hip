@@ -90,6 +90,7 @@ struct pt_context {
     int node_vote = 8;
     int vote_shade = 44, vote_node = 16;
     int sched_blocks_per_cu = 0;
+    int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
     int backend = 0;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
     int trace_blocks_per_cu = 0, shade_blocks_per_cu = 0;
     float4 *wf_state = nullptr;            // 5 float4 arrays of wf_slots entries
@@ -480,6 +481,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->sched_blocks_per_cu = std::max(1, bpc);
     if (const char *env = std::getenv("PTRACE_BACKEND"))
         ctx->backend = std::strcmp(env, "mega") == 0 ? 0 : 1;
+    if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : 4;
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_NODE")) ctx->vote_node = std::max(1, std::min(64, std::atoi(env)));
@@ -687,7 +689,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !ctx->d_mesh_mat) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, 256, ctx->stream));
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-    int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * ctx->sched_blocks_per_cu);
+    const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, ctx->sched_blocks_per_cu) : ctx->sched_blocks_per_cu;
+    int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * per_cu);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
     a.lane_state = ctx->d_lane_state;
@@ -860,6 +863,11 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
     if (std::strcmp(name, "bvh_width") == 0) {
         if (value != 2 && value != 4) return fail(ctx, PT_ERR_INVALID, "pt_set_option: bvh_width must be 2 or 4");
         ctx->bvh_width = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "blocks_per_cu") == 0) {
+        if (value < 0 || value > 16) return fail(ctx, PT_ERR_INVALID, "pt_set_option: blocks_per_cu must be 0..16");
+        ctx->blocks_per_cu = value;
         return PT_OK;
     }
     if (std::strcmp(name, "refit") == 0) {
