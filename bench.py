@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=16, help="samples per pixel per GPU per step")
     ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="contexts per GPU that render alternate steps on their own streams, so that one dispatch's "
+                         "ramp-up and tail are filled by the next (1 = one dispatch at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-stereo", action="store_true", help="skip the 1080p stereo frame time (2 eyes, 1 spp, 4 bounces)")
@@ -117,24 +120,41 @@ def main():
     W, H = args.width, args.height
     scene = pa.Scene(args.scene)
     sky = pa.procedural_sky(2048, 1024)
-    tr = pa.PathTracer(local_rank)
-    tr.load_scene(scene, sky)
-    tr.resize(W, H)
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # this rank's fresh frame ("Result")
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # this rank's sum over its steps ("Result1")
-    tr.bind_target(pa.PT_TARGET_RESULT, frame.data_ptr())
-    tr.bind_target(pa.PT_TARGET_CONVERGED, accum.data_ptr())
-    tr.set_stream(torch.cuda.current_stream().cuda_stream)
+    # Every context is one "ComputeShader instance" with its own targets and stream.  A dispatch's persistent grid
+    # fills the GPU, but its ramp-up and above all its tail (lanes finishing their last pixel) leave slots empty;
+    # with several dispatches queued on different streams the next one's blocks move in as slots free up.
+    n_ctx = max(1, min(args.in_flight, args.steps))
+    trs, accums, streams = [], [], []
+    for i in range(n_ctx):
+        t = pa.PathTracer(local_rank)
+        t.load_scene(scene, sky)
+        t.resize(W, H)
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")   # this context's sum over its steps ("Result1")
+        t.bind_target(pa.PT_TARGET_CONVERGED, acc.data_ptr())
+        st_i = torch.cuda.Stream()
+        t.set_stream(st_i.cuda_stream)
+        t.trace_rays(np.array([[0, 5, 0, 0, -1, 0]], np.float32))   # builds the acceleration structure now, not inside a timed step
+        trs.append(t); accums.append(acc); streams.append(st_i)
+    tr = trs[0]
+    total = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")     # this rank's sum; on rank 0 the job's sum
 
     def run(first, count):
-        """`count` steps: every rank adds its frames into its own accumulation buffer inside the kernel's final write
-        (sample indices first*world + rank, ... -> distinct seeds), then ONE sum-reduce of the buffers to rank 0."""
+        """`count` steps, dealt round-robin to the contexts: each adds its frames into its own accumulation buffer
+        inside the kernel's final write (sample indices (first + j)*world + rank -> distinct seeds); then the
+        buffers are added up and ONE sum-reduce takes them to rank 0."""
         for j in range(count):
             p = pa.make_params(scene, W, H, seed=pa.frame_seed((first + j) * world + rank), spp=args.spp,
-                               max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=j)
-            tr.render(p)
+                               max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=j // n_ctx)
+            trs[j % n_ctx].render(p)
+        cur = torch.cuda.current_stream()
+        used = min(n_ctx, count)
+        for i in range(used):
+            cur.wait_stream(streams[i])
+        total.zero_()
+        for i in range(used):
+            total.add_(accums[i])
         if dist is not None:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
         if dist is not None:
@@ -143,12 +163,24 @@ def main():
 
     run(0, args.warmup)             # also warms the collective up
     fence()
-    tr.stats()                      # close the statistics epoch of the warm-up
+    for t in trs:
+        t.stats()                   # close the statistics epoch of the warm-up
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
-    st = tr.stats()
+    sts = [t.stats() for t in trs]
+    st = dict(sts[0])
+    for k in ("rays", "nodes_visited", "prims_tested", "paths"):
+        st[k] = sum(x[k] for x in sts)
+    img_sum = total.clone() if rank == 0 else None
+    # The dominant kernel by itself: the same launches one at a time on one context, timed by HIP events on its stream.
+    # (In the region above up to n_ctx launches overlap, so a launch there lasts longer than it keeps the GPU busy.)
+    solo_launches = 3
+    for j in range(solo_launches):
+        tr.render(pa.make_params(scene, W, H, seed=pa.frame_seed((args.warmup + j) * world + rank), spp=args.spp,
+                                 max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=j))
+    solo = tr.stats()
 
     t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["rays"], st["nodes_visited"], st["prims_tested"], st["paths"]], dtype=torch.float64, device="cuda")
@@ -159,14 +191,17 @@ def main():
     rays, nodes, prims, paths = [float(x) for x in counts.tolist()]
 
     if rank == 0:
-        img = (accum / float(args.steps * world * 1.0)).cpu().numpy()   # every frame is already a mean over --spp samples
+        img = (img_sum / float(args.steps * world * 1.0)).cpu().numpy()   # every frame is already a mean over --spp samples
         mrays = rays / dt / 1e6
-        # dominant kernel = path_kernel; its launches are back to back on the stream, kernel_ms spans them
+        # roofline of the dominant kernel, path_sched_kernel<4>, from the solo launches: counted bytes per launch over the
+        # launch duration.  roofline["pipelined"] is the rate over the timed region, where n_ctx launches overlap.
         launches = args.steps
-        kernel_ms = st["kernel_ms"] / launches
-        r_rank = st["rays"]
-        alg_bytes = (st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES) / launches + W * H * PIXEL_BYTES
+        kernel_ms = solo["kernel_ms"] / solo_launches
+        r_rank = solo["rays"]
+        alg_bytes = (solo["nodes_visited"] * NODE_BYTES + solo["prims_tested"] * PRIM_BYTES) / solo_launches + W * H * PIXEL_BYTES
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        pipe_bytes = st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES + launches * W * H * PIXEL_BYTES
+        pipe_achieved = pipe_bytes / dt / 1e9
         out = {
             "metric": "Mrays/s (all bounces)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -178,12 +213,14 @@ def main():
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
-                         "kernel": "path_sched_kernel<4>", "kernel_ms": kernel_ms,
+                         "kernel": "path_sched_kernel<4>", "kernel_ms": kernel_ms, "launches_timed": solo_launches,
+                         "pipelined": {"launches_in_flight": n_ctx, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBS,
+                                       "effective_ms_per_launch": dt / launches * 1e3},
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_ray": (st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES) / max(1, r_rank),
-                         "nodes_per_ray": st["nodes_visited"] / max(1, r_rank),
-                         "prims_per_ray": st["prims_tested"] / max(1, r_rank),
-                         "kernel_mrays_per_s": r_rank / launches / (kernel_ms * 1e-3) / 1e6},
+                         "bytes_per_ray": (solo["nodes_visited"] * NODE_BYTES + solo["prims_tested"] * PRIM_BYTES) / max(1, r_rank),
+                         "nodes_per_ray": solo["nodes_visited"] / max(1, r_rank),
+                         "prims_per_ray": solo["prims_tested"] / max(1, r_rank),
+                         "kernel_mrays_per_s": r_rank / solo_launches / (kernel_ms * 1e-3) / 1e6},
             "image_mean_rgb": [float(x) for x in img[..., :3].reshape(-1, 3).mean(axis=0)],
             "image_crc": int(np.bitwise_xor.reduce(np.ascontiguousarray(img).view(np.uint32).reshape(-1))),
             "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
@@ -206,7 +243,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, args)
         print(json.dumps(out), flush=True)
-    tr.close()
+    for t in trs:
+        t.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
