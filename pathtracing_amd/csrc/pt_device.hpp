@@ -49,7 +49,10 @@ struct RenderArgs {
     int32_t *hit_ids;
     int32_t accumulate;
     uint32_t sample_index;
-    uint32_t *work_counter;
+    uint32_t *work_counter;       // kWorkShards counters, kWorkStride words apart; counter s hands out the work items
+                                  // s * shard_items ... (s + 1) * shard_items - 1
+    uint32_t shard_items;         // a multiple of 64 (whole 8x8 pixel blocks)
+    int32_t n_shards;             // 1 .. kWorkShards counters in use
     uint32_t *stack_overflow;     // kStackOverflow * (threads in the grid) entries
     float4 *lane_state;           // path_sched_kernel: 4 float4 per thread of the grid
     unsigned long long *stats;    // [0] rays [1] nodes [2] prims [3] paths
@@ -81,6 +84,9 @@ struct RenderArgs {
 };
 
 constexpr int kBlock = 256;            // 4 waves
+constexpr int kWorkShards = 64;        // most counters a frame is split over: one hot counter serialises the pixel claims
+                                       // of a 1-spp frame at the L2, many counters scatter the waves over the image
+constexpr int kWorkStride = 16;        // u32 words between counters: one cache line each
 constexpr int kStackLds = 16;          // traversal stack entries kept in LDS per lane
 constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 96 >= the deepest stack:
                                        // kMaxDepth (60) pushes for two-child nodes, 3 * ceil(60 / 2) for four-child nodes
@@ -714,6 +720,8 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
     float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
     int32_t node = kIdleNode; int sp = 0;
     uint32_t ray_work = 0;                // nodes | prims << 16 of the current ray
+    int shard = (int)(blockIdx.x % (uint32_t)a.n_shards);   // wave-uniform: which part of the frame this wave draws pixels from
+    bool frame_drained = false;
     *ls3 = make_int4(0, 0, 0, 0);
 #ifdef PT_PROFILE_PHASES
     uint32_t ph_rounds[3] = {0, 0, 0}, ph_lanes[3] = {0, 0, 0};   // wave-uniform
@@ -812,17 +820,30 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     }
                 }
             }
-            // ---- new pixels for lanes without one
+            // ---- new pixels for lanes without one.  The wave claims them from its current shard of the frame with one
+            // atomic; a shard that runs dry sends the wave on to the next one, for good.
             const bool need = was_idle || finished;
             unsigned long long m = __ballot(need);
             if (m) {
-                int leader = __ffsll((long long)m) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(a.work_counter, (uint32_t)__popcll(m));
-                base = __shfl(base, leader);
+                uint32_t item = 0; bool got = false;
+                int tries = 0;
+                while (m && !frame_drained) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(a.work_counter + shard * kWorkStride, (uint32_t)__popcll(m));
+                    base = __shfl(base, leader);
+                    const uint32_t sbeg = (uint32_t)shard * a.shard_items;
+                    const uint32_t send = min(sbeg + a.shard_items, a.total_items);
+                    const uint32_t mine = sbeg + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (need && !got && mine < send && base < a.shard_items) { item = mine; got = true; }
+                    m = __ballot(need && !got);
+                    if (m) {
+                        shard = shard + 1 == a.n_shards ? 0 : shard + 1;
+                        if (++tries == a.n_shards) frame_drained = true;   // every shard is empty: stop asking
+                    }
+                }
                 if (need) {
-                    uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (item >= a.total_items) {
+                    if (!got) {
                         no_more = true;
                     } else {
                         int x, y;
