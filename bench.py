@@ -259,9 +259,9 @@ def stereo_frame_time(pa, torch, frames=30):
     for _ in range(2):
         t = pa.PathTracer(torch.cuda.current_device())
         t.load_scene(scene, sky); t.resize(1920, 1080)
-        # each eye's persistent grid takes a quarter of the resident-block slots, so the two dispatches run side by side
-        # and each fills the other's ramp-up and tail (measured: 1.34 ms with full grids one after the other)
-        t.set_option("blocks_per_cu", int(os.environ.get("STEREO_BLOCKS", "1")))
+        # each eye's persistent grid takes half of the resident-block slots, so the two dispatches run side by side
+        # and each fills the other's ramp-up and tail (measured: 0.75 ms with full grids one after the other)
+        t.set_option("blocks_per_cu", int(os.environ.get("STEREO_BLOCKS", "2")))
         eyes.append(t)
     sep = 0.022
     def frame(k):
@@ -284,7 +284,7 @@ def stereo_frame_time(pa, torch, frames=30):
     for t in eyes:
         t.close()
     return {"ms_per_frame": ms, "frames": frames, "config": "xr scene, 2 x 1920x1080, 1 spp, 4 bounces, mean accumulation, 1 GPU, one context and stream per eye, "
-                      "blocks_per_cu 1 each (the two dispatches overlap)"}
+                      "blocks_per_cu 2 each (the two dispatches overlap)"}
 
 
 def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False):

@@ -162,7 +162,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *   "bvh_width"  4 (default): four-child nodes with 8-bit boxes; 2: two-child nodes with float boxes.
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most
  *                n blocks per compute unit, which leaves room for another context's dispatch to run alongside
- *                (two eyes of a stereo pair on one GPU: 1 each).
+ *                (two eyes of a stereo pair on one GPU: 2 each).
  *   "refit"      1 (default): pt_update_transforms refits the four-wide tree on the device; 0: it rebuilds on the host.
  * All combinations produce the same image bit for bit. */
 int pt_set_option(pt_context *ctx, const char *name, int value);
