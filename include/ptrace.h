@@ -90,7 +90,8 @@ enum {
     PT_TARGET_RESULT = 0,     /* "Result"  (RayTracingMaster.cs:740)  RGBA32F W*H */
     PT_TARGET_CONVERGED = 1,  /* "Result1" (RayTracingMaster.cs:741)  RGBA32F W*H */
     PT_TARGET_HIT_IDS = 2,    /* int32 W*H primary-hit ids; no counterpart in the reference (parity aid) */
-    PT_TARGET_DENOISED = 3    /* "Result2" (RayTracingMaster.cs:743, denoisedTex)  RGBA32F W*H; renderMode 0 */
+    PT_TARGET_DENOISED = 3,   /* "Result2" (RayTracingMaster.cs:743, denoisedTex)  RGBA32F W*H; renderMode 0 */
+    PT_TARGET_DISPLAY = 4     /* the `destination` of the display blit (RayTracingMaster.cs:764)  RGBA32F W*H   */
 };
 
 /* Per-dispatch uniforms: what SetShaderParameters() (RayTracingMaster.cs:455-540)
@@ -242,6 +243,12 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
  * shows the sky), or (0,0,0,1) when that position is off screen.  Result1 is read as it was before the
  * dispatch.  Whole frames only; accumulate must be PT_ACCUM_NONE. */
 int pt_render(pt_context *ctx, const PtFrameParams *params);
+
+/* Graphics.Blit(_target, destination, denoiser) (RayTracingMaster.cs:760-764, the imageBlur switch):
+ * Assets/Shaders/Denoiser.shader over Result into the display target.  The shader samples through tex2D;
+ * here that is bilinear filtering with float weights, clamp addressing and texel centres at (i + 0.5) / size,
+ * and the fixed4 output stays float.  Asynchronous, ordered after the renders issued so far. */
+int pt_display_denoise(pt_context *ctx);
 
 int pt_sync(pt_context *ctx);
 

@@ -504,6 +504,67 @@ static void denoiser(const float *result1, int W, int H, float fx, float fy, flo
     out4[3] = 0.0f;
 }
 
+/* ---- Assets/Shaders/Denoiser.shader (the display blit, RayTracingMaster.cs:760-764) ----
+ * tex2D is taken as: bilinear, float weights, clamp addressing, texel centres at (i + 0.5) / size. */
+static void tex2d(const float *tex, int W, int H, float u, float v, float *out4)
+{
+    float px = u * (float)W - 0.5f, py = v * (float)H - 0.5f;
+    float x0f = pt_floor(px), y0f = pt_floor(py);
+    float fx = px - x0f, fy = py - y0f;
+    int x0 = (int)pt_min(pt_max(x0f, 0.0f), (float)(W - 1)), x1 = (int)pt_min(pt_max(x0f + 1.0f, 0.0f), (float)(W - 1));
+    int y0 = (int)pt_min(pt_max(y0f, 0.0f), (float)(H - 1)), y1 = (int)pt_min(pt_max(y0f + 1.0f, 0.0f), (float)(H - 1));
+    const float *c00 = tex + 4 * ((size_t)y0 * W + x0), *c10 = tex + 4 * ((size_t)y0 * W + x1);
+    const float *c01 = tex + 4 * ((size_t)y1 * W + x0), *c11 = tex + 4 * ((size_t)y1 * W + x1);
+    for (int k = 0; k < 4; k++) {
+        float a = c00[k] + fx * (c10[k] - c00[k]);
+        float b = c01[k] + fx * (c11[k] - c01[k]);
+        out4[k] = a + fy * (b - a);
+    }
+}
+
+/* Denoiser.shader:50-184 for the fragment at pixel (x, y); `src` is _MainTex (= Result). */
+static void display_denoiser(const float *src, int W, int H, int x, int y, float *out4)
+{
+    const float c_phi = 1.0f, r_phi = 1.0f, n_phi = 0.5f, p_phi = 0.25f;
+    float fw = (float)W, fh = (float)H;
+    float u = ((float)x + 0.5f) / fw, v = ((float)y + 0.5f) / fh;                     /* i.uv at the pixel centre */
+    float cv[4];
+    tex2d(src, W, H, u, v, cv);                                                       /* :124-126 */
+    f3 cval = pt_make3(cv[0], cv[1], cv[2]), rval = cval, nval = cval;
+    float strength = (1.0f + (4.0f - 1.0f) * hash1((641.128752f * u + 312.321374f * v) + 1.92357812f)) * 1.0f;   /* :136 */
+    f3 sum = pt_make3(0, 0, 0), sum_f = pt_make3(0, 0, 0);
+    float cum_w = 0.0f, cum_fw = 0.0f;
+    for (int i = 0; i < 25; i++) {
+        float ox = (float)(i % 5 - 2), oy = (float)(i / 5 - 2);
+        float kern = k_atrous[i % 5] * k_atrous[i / 5];
+        float tv[4];
+        tex2d(src, W, H, u + ox * strength / fw, v + oy * strength / fh, tv);         /* :144-147 */
+        f3 ctmp = pt_make3(tv[0], tv[1], tv[2]), ntmp = ctmp, rtmp = ctmp;            /* :147,153,159: the same texture */
+        f3 t = pt_sub3(cval, ctmp);
+        float dist2 = pt_dot3(t, t);
+        float c_w = pt_min(pt_exp(-(dist2) / c_phi), 1.0f);                           /* :150 */
+        t = pt_sub3(nval, ntmp);
+        dist2 = pt_max(pt_dot3(t, t), 0.0f);
+        float n_w = pt_min(pt_exp(-(dist2) / n_phi), 1.0f);                           /* :156 */
+        t = pt_sub3(rval, rtmp);
+        dist2 = pt_dot3(t, t);
+        float r_w = pt_min(pt_exp(-(dist2) / r_phi), 1.0f);                           /* :162 */
+        float weight0 = c_w * n_w;
+        sum.x += ctmp.x * weight0 * kern; sum.y += ctmp.y * weight0 * kern; sum.z += ctmp.z * weight0 * kern;
+        cum_w += weight0 * kern;
+        float weight1 = r_w * n_w;
+        sum_f.x += rtmp.x * weight1 * kern; sum_f.y += rtmp.y * weight1 * kern; sum_f.z += rtmp.z * weight1 * kern;
+        cum_fw += weight1 * kern;
+    }
+    f3 a = pt_make3(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w);
+    f3 b = pt_make3(sum_f.x / cum_fw, sum_f.y / cum_fw, sum_f.z / cum_fw);
+    float p_w = pt_min(pt_exp(-(pt_dot3(a, a)) / p_phi), 1.0f);                       /* :177-181 */
+    out4[0] = pt_min(pt_max(a.x + p_w * (b.x - a.x), 0.0f), 1.0f);                    /* :183 */
+    out4[1] = pt_min(pt_max(a.y + p_w * (b.y - a.y), 0.0f), 1.0f);
+    out4[2] = pt_min(pt_max(a.z + p_w * (b.z - a.z), 0.0f), 1.0f);
+    out4[3] = 0.0f;
+}
+
 static f3 encode_pal_yuv(f3 rgb)                                                 /* SH:624-632 */
 {
     rgb = pt_make3(pt_pow_2(rgb.x), pt_pow_2(rgb.y), pt_pow_2(rgb.z));
@@ -970,6 +1031,14 @@ void pto_bilinear_sample(const float *result1, int W, int H, float px, float py,
 
 void pto_denoiser(const float *result1, int W, int H, int x, int y, float seed, float *out4) { denoiser(result1, W, H, (float)x, (float)y, seed, out4); }
 void pto_taa(const float *result1, const float *current, int W, int H, int x, int y, float *out4) { taa(result1, current, W, H, (float)x, (float)y, out4); }
+
+void pto_display_denoise(const float *result, int W, int H, float *display, int threads)
+{
+    if (threads <= 0) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) display_denoiser(result, W, H, x, y, display + 4 * ((size_t)y * W + x));
+}
 
 float pto_fmath(int which, float a, float b)
 {

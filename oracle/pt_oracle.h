@@ -89,6 +89,8 @@ void pto_find_camera_ray(const PtCameraHistory *old_camera, int width, int heigh
 void pto_bilinear_sample(const float *result1, int width, int height, float px, float py, float *out4);            /* SH:440-463 */
 void pto_denoiser(const float *result1, int width, int height, int x, int y, float seed, float *out4);             /* SH:479-615 */
 void pto_taa(const float *result1, const float *current, int width, int height, int x, int y, float *out4);        /* SH:644-714 */
+/* Assets/Shaders/Denoiser.shader over a whole image (the display blit, RayTracingMaster.cs:760-764). */
+void pto_display_denoise(const float *result, int width, int height, float *display, int threads);
 float pto_fmath(int which, float a, float b); /* 0 sin 1 cos 2 pow 3 acos 4 atan2 5 log2 6 exp2 7 exp 8 frac */
 
 #ifdef __cplusplus

@@ -59,6 +59,7 @@ def lib():
         L.pto_path_dump.argtypes = [C.c_void_p, C.POINTER(PtFrameParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.pto_find_camera_ray.argtypes = [C.POINTER(PtCameraHistory), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.pto_bilinear_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.pto_display_denoise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.pto_fmath.restype = C.c_float
         L.pto_fmath.argtypes = [C.c_int, C.c_float, C.c_float]
         _lib = L
@@ -192,4 +193,10 @@ def denoiser(result1, x, y, seed):
 def taa(result1, current, x, y):
     a = np.ascontiguousarray(result1, np.float32); b = np.ascontiguousarray(current, np.float32); out = np.zeros(4, np.float32)
     lib().pto_taa(a.ctypes.data, b.ctypes.data, a.shape[1], a.shape[0], x, y, out.ctypes.data)
+    return out
+
+
+def display_denoise(result, threads=4):
+    img = np.ascontiguousarray(result, np.float32); out = np.zeros_like(img)
+    lib().pto_display_denoise(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data, threads)
     return out

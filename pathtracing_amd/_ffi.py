@@ -51,7 +51,7 @@ assert C.sizeof(PtSphere) == 56 and C.sizeof(PtMeshObject) == 72 and C.sizeof(Pt
 PT_LOBE_PHONG, PT_LOBE_GGX = 0, 1
 
 PT_ACCUM_NONE, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_ACCUM_ADDMAT = 0, 1, 2, 3
-PT_TARGET_RESULT, PT_TARGET_CONVERGED, PT_TARGET_HIT_IDS, PT_TARGET_DENOISED = 0, 1, 2, 3
+PT_TARGET_RESULT, PT_TARGET_CONVERGED, PT_TARGET_HIT_IDS, PT_TARGET_DENOISED, PT_TARGET_DISPLAY = 0, 1, 2, 3, 4
 
 _P = C.POINTER
 _ctx = C.c_void_p
@@ -72,6 +72,7 @@ PTRACE_SYMBOLS = {
     "pt_resize": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "pt_bind_target": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "pt_render": (C.c_int, [_ctx, _P(PtFrameParams)]),
+    "pt_display_denoise": (C.c_int, [_ctx]),
     "pt_sync": (C.c_int, [_ctx]),
     "pt_read_result": (C.c_int, [_ctx, C.c_void_p]),
     "pt_read_converged": (C.c_int, [_ctx, C.c_void_p]),

@@ -142,6 +142,71 @@ __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void taa_kernel(cons
     a.result[(size_t)y * a.W + x] = make_float4(aa.x, aa.y, aa.z, mixRate);                  // SH:713, SH:929
 }
 
+// ---- the display pass Assets/Shaders/Denoiser.shader (Graphics.Blit(_target, destination, denoiser),
+// RayTracingMaster.cs:760-764, when imageBlur is on) ----
+//
+// A fragment shader: the same 25-tap filter as above, but on `Result` through tex2D with normalised
+// coordinates, weights c_w * n_w with n_w from the same colour difference at n_phi = 0.5 (:153-156), and a
+// stride hash without _Seed (:136).  What the shader leaves to the sampler is fixed here as: bilinear
+// filtering with full float weights, clamp addressing, texel centres at (i + 0.5) / size; the fixed4
+// return value is kept in float.
+
+// tex2D(_MainTex, uv) under those rules.
+__device__ __forceinline__ float4 tex2d_bilinear_clamp(const float4 *tex, int W, int H, float u, float v)
+{
+    const float px = u * (float)W - 0.5f, py = v * (float)H - 0.5f;
+    const float x0f = pt_floor(px), y0f = pt_floor(py);
+    const float fx = px - x0f, fy = py - y0f;
+    const int x0 = (int)fminf(fmaxf(x0f, 0.0f), (float)(W - 1)), x1 = (int)fminf(fmaxf(x0f + 1.0f, 0.0f), (float)(W - 1));
+    const int y0 = (int)fminf(fmaxf(y0f, 0.0f), (float)(H - 1)), y1 = (int)fminf(fmaxf(y0f + 1.0f, 0.0f), (float)(H - 1));
+    const float4 c00 = tex[(size_t)y0 * W + x0], c10 = tex[(size_t)y0 * W + x1];
+    const float4 c01 = tex[(size_t)y1 * W + x0], c11 = tex[(size_t)y1 * W + x1];
+    const float4 a = make_float4(lerp1(c00.x, c10.x, fx), lerp1(c00.y, c10.y, fx), lerp1(c00.z, c10.z, fx), lerp1(c00.w, c10.w, fx));
+    const float4 b = make_float4(lerp1(c01.x, c11.x, fx), lerp1(c01.y, c11.y, fx), lerp1(c01.z, c11.z, fx), lerp1(c01.w, c11.w, fx));
+    return make_float4(lerp1(a.x, b.x, fy), lerp1(a.y, b.y, fy), lerp1(a.z, b.z, fy), lerp1(a.w, b.w, fy));
+}
+
+// Denoiser.shader:50-184 + frag (:186-215); src = Result, dst = the display image.
+__global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void display_denoise_kernel(const float4 *src, float4 *dst, int W, int H)
+{
+    const int x = blockIdx.x * kScreenBlockX + threadIdx.x, y = blockIdx.y * kScreenBlockY + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const float fw = (float)W, fh = (float)H;
+    const float u = ((float)x + 0.5f) / fw, v = ((float)y + 0.5f) / fh;     // the interpolated i.uv at the pixel centre
+    const float c_phi = 1.0f, r_phi = 1.0f, n_phi = 0.5f, p_phi = 0.25f;
+    const float4 c4 = tex2d_bilinear_clamp(src, W, H, u, v);                // :124-126, cval = rval = nval
+    const f3 cval = pt_make3(c4.x, c4.y, c4.z);
+    const float strength = (1.0f + (4.0f - 1.0f) * hash1((641.128752f * u + 312.321374f * v) + 1.92357812f)) * 1.0f;   // :136
+    f3 sum = pt_make3(0, 0, 0), sum_f = pt_make3(0, 0, 0);
+    float cum_w = 0.0f, cum_fw = 0.0f;
+    const float kw[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const float kern = kw[i] * kw[j];
+            const float4 t4 = tex2d_bilinear_clamp(src, W, H, u + (float)(i - 2) * strength / fw, v + (float)(j - 2) * strength / fh);   // :144-147
+            const f3 ctmp = pt_make3(t4.x, t4.y, t4.z);
+            const f3 t = pt_sub3(cval, ctmp);
+            const float dist2 = pt_dot3(t, t);
+            const float c_w = pt_min(pt_exp(-(dist2) / c_phi), 1.0f);                 // :150
+            const float n_w = pt_min(pt_exp(-(pt_max(dist2, 0.0f)) / n_phi), 1.0f);   // :153-156, ntmp = ctmp
+            const float r_w = pt_min(pt_exp(-(dist2) / r_phi), 1.0f);                 // :159-162, rtmp = ctmp
+            const float weight0 = c_w * n_w;
+            sum.x += ctmp.x * weight0 * kern; sum.y += ctmp.y * weight0 * kern; sum.z += ctmp.z * weight0 * kern;
+            cum_w += weight0 * kern;
+            const float weight1 = r_w * n_w;
+            sum_f.x += ctmp.x * weight1 * kern; sum_f.y += ctmp.y * weight1 * kern; sum_f.z += ctmp.z * weight1 * kern;
+            cum_fw += weight1 * kern;
+        }
+    }
+    const f3 a = pt_make3(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w);
+    const f3 b = pt_make3(sum_f.x / cum_fw, sum_f.y / cum_fw, sum_f.z / cum_fw);
+    const float p_w = pt_min(pt_exp(-(pt_dot3(a, a)) / p_phi), 1.0f);                 // :177-181
+    dst[(size_t)y * W + x] = make_float4(pt_min(pt_max(lerp1(a.x, b.x, p_w), 0.0f), 1.0f), pt_min(pt_max(lerp1(a.y, b.y, p_w), 0.0f), 1.0f),
+                                         pt_min(pt_max(lerp1(a.z, b.z, p_w), 0.0f), 1.0f), 0.0f);   // :183
+}
+
 // ---- renderMode 5 / 6: pixels outside the stripe being rendered (SH:742-789) ----
 
 struct StripeArgs {

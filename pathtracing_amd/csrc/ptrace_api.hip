@@ -67,6 +67,7 @@ struct pt_context {
     // targets
     int W = 0, H = 0;
     float4 *own_result = nullptr, *own_conv = nullptr, *own_result2 = nullptr;
+    float4 *own_display = nullptr, *display = nullptr;   // the display blit's destination (pt_display_denoise), made on first use
     float4 *result2 = nullptr;                     // "Result2" (denoisedTex): renderMode 0's accumulated radiance
     float4 *d_filtered = nullptr;                  // renderMode 0 scratch: the denoised image, and
     float *d_seeds = nullptr;                      //   every pixel's running _Seed
@@ -498,7 +499,7 @@ void pt_destroy(pt_context *ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
-    free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
+    free_dev(ctx->d_filtered); free_dev(ctx->d_seeds); free_dev(ctx->own_display);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
@@ -643,6 +644,8 @@ int pt_resize(pt_context *ctx, int width, int height)
                rebind_i = ctx->ids == ctx->own_ids, rebind_2 = ctx->result2 == ctx->own_result2;
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
+    if (ctx->display == ctx->own_display) ctx->display = nullptr;
+    free_dev(ctx->own_display);
     ctx->screen_pixels = 0;
     size_t n = (size_t)width * height;
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_result2, n * sizeof(float4)));
@@ -672,6 +675,7 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
     case PT_TARGET_CONVERGED: ctx->conv = device_ptr ? (float4 *)device_ptr : ctx->own_conv; break;
     case PT_TARGET_HIT_IDS: ctx->ids = device_ptr ? (int32_t *)device_ptr : ctx->own_ids; break;
     case PT_TARGET_DENOISED: ctx->result2 = device_ptr ? (float4 *)device_ptr : ctx->own_result2; break;
+    case PT_TARGET_DISPLAY: ctx->display = device_ptr ? (float4 *)device_ptr : ctx->own_display; break;
     default: return fail(ctx, PT_ERR_INVALID, "pt_bind_target: unknown target");
     }
     return PT_OK;
@@ -895,6 +899,24 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
     return fail(ctx, PT_ERR_INVALID, std::string("pt_set_option: unknown option ") + name);
 }
 
+int pt_display_denoise(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_display_denoise before pt_resize");
+    DeviceGuard g(ctx->device);
+    if (!ctx->display) {
+        if (!ctx->own_display) {
+            PT_HIP(ctx, hipMalloc((void **)&ctx->own_display, (size_t)ctx->W * ctx->H * sizeof(float4)));
+            PT_HIP(ctx, hipMemsetAsync(ctx->own_display, 0, (size_t)ctx->W * ctx->H * sizeof(float4), ctx->stream));
+        }
+        ctx->display = ctx->own_display;
+    }
+    const dim3 blk(kScreenBlockX, kScreenBlockY), grd((ctx->W + kScreenBlockX - 1) / kScreenBlockX, (ctx->H + kScreenBlockY - 1) / kScreenBlockY);
+    hipLaunchKernelGGL(display_denoise_kernel, grd, blk, 0, ctx->stream, (const float4 *)ctx->result, ctx->display, ctx->W, ctx->H);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 int pt_sync(pt_context *ctx)
 {
     if (!ctx) return PT_ERR_INVALID;
@@ -942,6 +964,7 @@ static float4 *target_of(pt_context *ctx, int which)
     case PT_TARGET_RESULT: return ctx->result;
     case PT_TARGET_CONVERGED: return ctx->conv;
     case PT_TARGET_DENOISED: return ctx->result2;
+    case PT_TARGET_DISPLAY: return ctx->display;
     default: return nullptr;
     }
 }

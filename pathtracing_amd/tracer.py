@@ -107,6 +107,10 @@ class PathTracer:
     def render(self, params):
         self._check(self._lib.pt_render(self._ctx, C.byref(params)), "pt_render")
 
+    def display_denoise(self):
+        """Denoiser.shader over Result into the display target (read it with read_target(PT_TARGET_DISPLAY))."""
+        self._check(self._lib.pt_display_denoise(self._ctx), "pt_display_denoise")
+
     def sync(self):
         self._check(self._lib.pt_sync(self._ctx), "pt_sync")
 

@@ -659,3 +659,20 @@ def test_mesh_materials_and_ggx_match_oracle(tracer, sky_small):
     bad = mats.copy(); bad["lobe"][0] = 7
     with pytest.raises(pa.PtraceError, match="lobe"):
         tracer.set_mesh_materials(bad)
+
+
+# ------------------------------------------- the display blit (Denoiser.shader)
+
+def test_display_denoise_matches_oracle(tracer, sky_small):
+    s = pa.Scene("fixture")
+    tracer.load_scene(s, sky_small)
+    for W, H in ((64, 36), (131, 77)):
+        tracer.resize(W, H)
+        tracer.render(pa.make_params(s, W, H, spp=2, max_bounces=4, seed=0.4))
+        tracer.display_denoise()
+        res = tracer.read_result()
+        got = tracer.read_target(pa.PT_TARGET_DISPLAY)
+        want = po.display_denoise(res)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), (W, H)
+        assert (tracer.read_result() == res).all()                  # Result itself is untouched
+        assert 0.5 * res[..., :3].clip(0, 1).mean() < got[..., :3].mean() < 1.5 * res[..., :3].clip(0, 1).mean()

@@ -588,3 +588,21 @@ def test_ggx_lobe_properties():
     scene, m = _one_quad_scene(((0, 0, 0), 0.999, (1, 1, 1), pa.PT_LOBE_PHONG))
     ph = po.Oracle(*scene, sky=sky, materials=m).render(p, W, H, threads=4)[0]
     assert abs(float(ph[..., :3].mean()) - means[0.999]) < 0.15   # the Phong lobe loses what it samples below the surface
+
+
+# ------------------------------------------- the display blit (Denoiser.shader)
+
+def test_display_denoiser_kat():
+    """Denoiser.shader: a constant image stays constant everywhere (clamp addressing: no dark border, unlike the
+    compute kernel's filter), values above 1 are clamped, alpha is 0, and an isolated outlier is suppressed by
+    the two colour weights exp(-d2) * exp(-d2 / 0.5)."""
+    W, H = 40, 30
+    img = np.zeros((H, W, 4), np.float32); img[..., :3] = (0.25, 0.5, 0.75); img[..., 3] = 3.0
+    out = po.display_denoise(img)
+    assert np.allclose(out[..., :3], (0.25, 0.5, 0.75), atol=1e-6) and (out[..., 3] == 0).all()
+    img[..., :3] = 1.5
+    assert (po.display_denoise(img)[..., :3] == 1.0).all()
+    img[..., :3] = 0.1; img[15, 20, :3] = 2.0
+    out = po.display_denoise(img)
+    assert out[15, 21, 0] < 0.1 + 1e-3 and out[15, 19, 0] < 0.1 + 1e-3          # neighbours ignore the outlier
+    assert out[15, 20, 0] > 0.9                                                 # the outlier's own centre tap dominates (and is clamped)
