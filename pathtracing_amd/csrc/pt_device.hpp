@@ -419,50 +419,54 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
                                       float t, int32_t id, uint32_t rec, f3 &hit_pos)
 {
     int lobe = PT_LOBE_PHONG;
-    if (!(t < PT_INF)) {
-        hit_pos = pt_make3(0, 0, 0);
-        f3 sky = sky_sample(sc, d);
-        result.x += energy.x * sky.x / fspp;
-        result.y += energy.y * sky.y / fspp;
-        result.z += energy.z * sky.z / fspp;
+    // What Shade() returns - the hit's emission, or the sky after a miss (SH:371-372) - is added once for all cases
+    // below: result += energy * value / spp (SH:866/870) is three correctly rounded divisions, and a wave with mixed
+    // hits would otherwise run them once per case.  Likewise the hit normal: every case leaves a vector that one
+    // normalize() turns into the shader's normal ((0,1,0) stays (0,1,0) exactly).
+    const bool hit = t < PT_INF;
+    f3 emitted, position = pt_make3(0, 0, 0), nraw = pt_make3(0, 1, 0), albedo = pt_make3(0, 0, 0), specular = pt_make3(0, 0, 0);
+    float smoothness = 0.0f;
+    if (!hit) {
+        emitted = sky_sample(sc, d);
+    } else {
+        position = pt_along3(o, t, d);
+        if (id == 0) {                                  // SH:162-166
+            albedo = pt_make3(0.5f, 0.5f, 0.5f);
+            specular = pt_make3(0.03f, 0.03f, 0.03f);
+            smoothness = 0.2f;
+            emitted = pt_make3(0, 0, 0);
+        } else if (id <= sc.n_spheres) {                // SH:184-188
+            const float4 *m = sc.sphere_mat + (size_t)(id - 1) * 4;
+            float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+            nraw = pt_sub3(position, xyz(m0));
+            albedo = xyz(m1); smoothness = m1.w;
+            specular = xyz(m2);
+            emitted = xyz(m3);
+        } else {                                        // SH:249-253
+            float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
+            nraw = pt_cross3(xyz(b), xyz(c));
+            if (MAT && sc.mesh_mat) {
+                const float4 *m = sc.mesh_mat + (size_t)as_i(c.w) * 3;
+                const float4 m0 = m[0], m1 = m[1], m2 = m[2];
+                albedo = xyz(m0); smoothness = m0.w;
+                specular = xyz(m1); lobe = as_i(m1.w);
+                emitted = xyz(m2);
+            } else {
+                specular = pt_make3(0.65f, 0.65f, 0.65f);
+                smoothness = 0.99f;
+                emitted = pt_make3(0, 0, 0);
+            }
+        }
+    }
+    hit_pos = position;
+    result.x += energy.x * emitted.x / fspp;
+    result.y += energy.y * emitted.y / fspp;
+    result.z += energy.z * emitted.z / fspp;
+    if (!hit) {
         energy = pt_make3(0, 0, 0);
         return;
     }
-    const f3 position = pt_along3(o, t, d);
-    hit_pos = position;
-    f3 normal, albedo, specular;
-    float smoothness;
-    if (id == 0) {                                  // SH:162-166
-        normal = pt_make3(0, 1, 0);
-        albedo = pt_make3(0.5f, 0.5f, 0.5f);
-        specular = pt_make3(0.03f, 0.03f, 0.03f);
-        smoothness = 0.2f;
-        // emission 0: result += energy * 0 / spp leaves result unchanged only if energy is finite;
-        // keep the shader's arithmetic
-        result.x += energy.x * 0.0f / fspp; result.y += energy.y * 0.0f / fspp; result.z += energy.z * 0.0f / fspp;
-    } else if (id <= sc.n_spheres) {                // SH:184-188
-        const float4 *m = sc.sphere_mat + (size_t)(id - 1) * 4;
-        float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
-        normal = pt_normalize3(pt_sub3(position, xyz(m0)));
-        albedo = xyz(m1); smoothness = m1.w;
-        specular = xyz(m2);
-        result.x += energy.x * m3.x / fspp; result.y += energy.y * m3.y / fspp; result.z += energy.z * m3.z / fspp;
-    } else {                                        // SH:249-253
-        float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
-        normal = pt_normalize3(pt_cross3(xyz(b), xyz(c)));
-        if (MAT && sc.mesh_mat) {
-            const float4 *m = sc.mesh_mat + (size_t)as_i(c.w) * 3;
-            const float4 m0 = m[0], m1 = m[1], m2 = m[2];
-            albedo = xyz(m0); smoothness = m0.w;
-            specular = xyz(m1); lobe = as_i(m1.w);
-            result.x += energy.x * m2.x / fspp; result.y += energy.y * m2.y / fspp; result.z += energy.z * m2.z / fspp;
-        } else {
-            albedo = pt_make3(0, 0, 0);
-            specular = pt_make3(0.65f, 0.65f, 0.65f);
-            smoothness = 0.99f;
-            result.x += energy.x * 0.0f / fspp; result.y += energy.y * 0.0f / fspp; result.z += energy.z * 0.0f / fspp;
-        }
-    }
+    const f3 normal = pt_normalize3(nraw);
     albedo = pt_make3(pt_min(1.0f - specular.x, albedo.x), pt_min(1.0f - specular.y, albedo.y),
                       pt_min(1.0f - specular.z, albedo.z));
     const float third = 1.0f / 3.0f;

@@ -6,7 +6,7 @@ cp pathtracing_amd/csrc/libptrace.so /tmp/libptrace_base.so
 for lib in base "$@"; do
   if [ "$lib" = base ]; then cp /tmp/libptrace_base.so pathtracing_amd/csrc/libptrace.so; else cp pathtracing_amd/csrc/$lib pathtracing_amd/csrc/libptrace.so; fi
   for rep in 1 2; do
-    PTRACE_BACKEND=${PTRACE_BACKEND:-mega} timeout -k 5 90 python -u bench.py --steps 4 --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['value'],1), round(d['ms_per_step'],3), d['image_mean_rgb'][0], d['image_crc'])" || exit 1
+    PTRACE_BACKEND=${PTRACE_BACKEND:-mega} timeout -k 5 90 python -u bench.py --steps 4 --warmup 1 --no-cpu-baseline --in-flight 1 $BENCH_ARGS 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['value'],1), round(d['ms_per_step'],3), d['image_mean_rgb'][0], d['image_crc'])" || exit 1
   done
 done
 cp /tmp/libptrace_base.so pathtracing_amd/csrc/libptrace.so
