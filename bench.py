@@ -238,6 +238,7 @@ def main():
         if not args.no_stereo and world == 1:
             out["blob70k_1080p"] = secondary_scene_rate(pa, torch, sky)
             out["ggx_1080p"] = secondary_scene_rate(pa, torch, sky, name=args.scene, ggx=True)
+            out["reuse_primary_hit"] = secondary_scene_rate(pa, torch, sky, name=args.scene, reuse=True)
         if not args.no_reproj and world == 1:
             out["reproj_1080p"] = reproj_frame_time(pa, torch, scene, sky)
         if world == 1 and not args.no_cpu_baseline:
@@ -287,13 +288,15 @@ def stereo_frame_time(pa, torch, frames=30):
                       "blocks_per_cu 2 each (the two dispatches overlap)"}
 
 
-def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False):
+def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False):
     """Mrays/s on another scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU): the ~70 k-triangle
     mesh, or (ggx) the bench scene with every mesh object given a GGX metal surface instead of the shader's
     hard-coded Phong one (PtMaterial, an extension)."""
     scene = pa.Scene(name)
     t = pa.PathTracer(torch.cuda.current_device())
     t.load_scene(scene, sky); t.resize(1920, 1080)
+    if reuse:   # option: a pixel's camera ray (the same for all its samples: the shader has no jitter) is traced once
+        t.set_option("reuse_primary_hit", 1)
     if ggx:
         t.set_mesh_materials(pa.materials([((0.0, 0.0, 0.0), 0.8, (0.95, 0.64, 0.54), pa.PT_LOBE_GGX)] * len(scene.objects)))
     t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(0), spp=16, max_bounces=8)); t.stats()
@@ -306,7 +309,8 @@ def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False):
     t.close()
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
             "config": f"{name} ({scene.n_triangles} triangles + spheres + plane{', GGX copper on every mesh' if ggx else ''}), "
-                      "1920x1080, 8 bounces, 16 spp, 1 GPU"}
+                      "1920x1080, 8 bounces, 16 spp, 1 GPU, one dispatch at a time"
+                      + (", option reuse_primary_hit: value counts only the rays actually traced (same image)" if reuse else "")}
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):

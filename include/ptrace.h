@@ -102,7 +102,7 @@ typedef struct PtFrameParams {
     float seed;                          /* _Seed                     RayTracingMaster.cs:530     */
     int32_t samples_per_pixel;           /* _SamplesPerPixel          RayTracingMaster.cs:531     */
     int32_t max_bounces;                 /* path segments per sample; the shader hard-codes 4
-                                            (RayTracingShader.compute:866-873); must be >= 1     */
+                                            (RayTracingShader.compute:866-873); 1..4095          */
     int32_t depth;                       /* _Depth                    RayTracingMaster.cs:532     */
     int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735,977-990): 1 = Default,
                                             2 = Reproj, 0 = Denoise, 5 = PartialFrameReproj,
@@ -164,6 +164,10 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most
  *                n blocks per compute unit, which leaves room for another context's dispatch to run alongside
  *                (two eyes of a stereo pair on one GPU: 2 each).
+ *   "reuse_primary_hit"  0 (default): every sample traces its camera ray, as the shader does; 1: a pixel's camera ray
+ *                is traced once per dispatch and its hit reused for the pixel's other samples - the shader applies no
+ *                jitter (RayTracingShader.compute:842), so the ray and its hit are the same every time.  Same image;
+ *                PtStats.rays then counts only the rays actually traced.
  *   "refit"      1 (default): pt_update_transforms refits the four-wide tree on the device; 0: it rebuilds on the host.
  * All combinations produce the same image bit for bit. */
 int pt_set_option(pt_context *ctx, const char *name, int value);

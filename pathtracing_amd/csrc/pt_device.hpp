@@ -71,6 +71,7 @@ struct RenderArgs {
     int32_t node_vote;            // wf_trace leaves the inner-node loop when fewer lanes than this hold an inner node
     int32_t vote_shade, vote_node; // path_sched_kernel phase thresholds
     // renderMode 2 (temporal reprojection, SH:950-983)
+    int32_t reuse_primary;        // option: trace a pixel's primary ray once and reuse its hit for the later samples
     int32_t render_mode;
     float accumulation_frames;    // (float)_AccumulationFrames
     float old_c2w[16];            // _CameraToWorldOld[0]
@@ -703,7 +704,7 @@ __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && n
 // struct-of-arrays, so a wave's accesses coalesce); only what traversal needs stays in registers.
 // That keeps the register count of the traversal phases, and with it the kernel's occupancy, down.
 //   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, t of the primary hit)
-//   ls2 = (pixel x | y << 16, sample, bounce, primary id)   ls3 = (rays, nodes, prims, paths) counters
+//   ls2 = (pixel x | y << 16, sample | bounce << 20, primary record, primary id)   ls3 = (rays, nodes, prims, paths) counters
 template <int WIDE, bool MAT>
 __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 {
@@ -755,12 +756,15 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             }
             const bool was_done = node == kDoneNode, was_idle = node == kIdleNode;
             bool new_ray = false, finished = false, no_more = false;
+            bool cached = false;                   // new_ray whose hit is already known (the pixel's primary hit)
+            float cached_t = PT_INF; int32_t cached_id = -1; uint32_t cached_rec = 0;
             int4 cnt = make_int4(0, 0, 0, 0);
             if (waiting) cnt = *ls3;
             if (was_done) {
                 const int4 px = *ls2;
                 const int pix_x = px.x & 0xffff, pix_y = px.x >> 16;
-                int sample = px.y, bounce = px.z, primary_id = px.w;
+                int sample = px.y & 0xfffff, bounce = (int)((uint32_t)px.y >> 20), primary_id = px.w;
+                uint32_t primary_rec = (uint32_t)px.z;
                 {
                     const uint32_t rw = (uint32_t)as_i(lds_save[threadIdx.x + 8 * kBlock]);
                     cnt.y += (int)(rw & 0xffffu); cnt.z += (int)(rw >> 16);
@@ -784,6 +788,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     bool path_done;
                     if (bounce == 0) {
                         primary_id = idbest;
+                        primary_rec = recbest;
                         t_primary = tbest;
                         path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see the note above
                     } else {
@@ -798,6 +803,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                             energy = pt_make3(1, 1, 1);
                             camera_ray(a, pix_x, pix_y, o, d);
                             cnt.w++;
+                            if (a.reuse_primary) {
+                                // SH:842 has no jitter: every sample of a pixel starts with the same camera ray, so
+                                // its Trace() (SH:859) returns the hit found for the first sample
+                                cached = true; cached_t = t_primary; cached_id = primary_id; cached_rec = primary_rec;
+                            }
                         } else {                                       // SH:933-936
                             // SH:860, SH:935: hitPos of the (last) sample's primary ray, (0,0,0) after a miss, and
                             // its distance from the camera; every sample of a pixel has the same primary ray
@@ -820,7 +830,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     if (new_ray) {
                         *ls0 = make_float4(energy.x, energy.y, energy.z, rs.seed);
                         *ls1 = make_float4(result.x, result.y, result.z, t_primary);
-                        *ls2 = make_int4(px.x, sample, bounce, primary_id);
+                        *ls2 = make_int4(px.x, sample | (bounce << 20), (int)primary_rec, primary_id);
                     }
                 }
             }
@@ -854,7 +864,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         if (item_pixel(a, item, x, y)) {
                             *ls0 = make_float4(1.0f, 1.0f, 1.0f, a.seed);
                             *ls1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            *ls2 = make_int4(x | (y << 16), 0, 0, -1);
+                            *ls2 = make_int4(x | (y << 16), 0, 0, -1);   // sample 0, bounce 0, no primary hit yet
                             camera_ray(a, x, y, o, d);
                             cnt.w++;
                             new_ray = true;
@@ -879,6 +889,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                 node = sc.n_nodes ? 0 : kDoneNode;
                 ray_work = 0;
                 cnt.x++;
+                if (cached) {                       // nothing to traverse: straight back to the shade queue
+                    tbest = cached_t; idbest = cached_id; recbest = cached_rec;
+                    node = kDoneNode;
+                    cnt.x--;
+                }
             }
             if (waiting) *ls3 = cnt;
             continue;

@@ -92,6 +92,7 @@ struct pt_context {
     int vote_shade = 44, vote_node = 16;
     int sched_blocks_per_cu = 0;
     int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
+    int reuse_primary = 0;                 // option "reuse_primary_hit"
     int backend = 0;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
     int trace_blocks_per_cu = 0, shade_blocks_per_cu = 0;
     float4 *wf_state = nullptr;            // 5 float4 arrays of wf_slots entries
@@ -690,7 +691,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     a.tiles_x = (tw + 7) / 8;
     const int tiles_y = (th + 7) / 8;
     a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
-    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !ctx->d_mesh_mat) return render_wavefront(ctx, a);
+    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !ctx->d_mesh_mat && !a.reuse_primary) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
     {
         // Few samples per pixel: pixels are claimed often, and one counter would serialise the claims at the L2.  Many
@@ -745,7 +746,8 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 0 (Denoise), 1 (Default), 2 (Reproj), 5 and 6 (PartialFrameReproj[Depth]) are implemented");
     if (mode != 1 && p->accumulate != PT_ACCUM_NONE)
         return fail(ctx, PT_ERR_INVALID, "pt_render: every renderMode but 1 uses the converged target as its history; accumulate must be PT_ACCUM_NONE");
-    if (p->max_bounces < 1) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be >= 1");
+    if (p->max_bounces < 1 || p->max_bounces > 4095) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be 1..4095");
+    if (p->samples_per_pixel >= (1 << 20)) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_pixel must be below 2^20 per dispatch");
     if (p->accumulate < PT_ACCUM_NONE || p->accumulate > PT_ACCUM_ADDMAT) return fail(ctx, PT_ERR_INVALID, "pt_render: bad accumulate mode");
     int x0 = 0, y0 = 0, tw = ctx->W, th = ctx->H;
     if (p->tile_w > 0 && p->tile_h > 0) { x0 = p->tile_x0; y0 = p->tile_y0; tw = p->tile_w; th = p->tile_h; }
@@ -785,6 +787,7 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     a.result = ctx->result; a.converged = ctx->conv; a.hit_ids = ctx->ids;
     a.accumulate = p->accumulate; a.sample_index = p->sample_index;
     a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
+    a.reuse_primary = ctx->reuse_primary;
     a.render_mode = stripes ? 1 : mode;   // the stripe being rendered is written as renderMode 1 writes (SH:933-936)
     a.history = ctx->conv;
     a.accumulation_frames = (float)p->accumulation_frames;
@@ -878,6 +881,11 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
     if (std::strcmp(name, "bvh_width") == 0) {
         if (value != 2 && value != 4) return fail(ctx, PT_ERR_INVALID, "pt_set_option: bvh_width must be 2 or 4");
         ctx->bvh_width = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "reuse_primary_hit") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: reuse_primary_hit must be 0 or 1");
+        ctx->reuse_primary = value;
         return PT_OK;
     }
     if (std::strcmp(name, "blocks_per_cu") == 0) {

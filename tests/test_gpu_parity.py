@@ -676,3 +676,29 @@ def test_display_denoise_matches_oracle(tracer, sky_small):
         assert (got.view(np.uint32) == want.view(np.uint32)).all(), (W, H)
         assert (tracer.read_result() == res).all()                  # Result itself is untouched
         assert 0.5 * res[..., :3].clip(0, 1).mean() < got[..., :3].mean() < 1.5 * res[..., :3].clip(0, 1).mean()
+
+
+def test_reuse_primary_hit_option(tracer, sky_small):
+    """The shader applies no jitter, so every sample of a pixel traces the same camera ray; with the option on that ray
+    is traced once per pixel.  Same image bit for bit, fewer rays: one primary per pixel instead of one per sample."""
+    s = pa.Scene("fixture")
+    tracer.load_scene(s, sky_small)
+    W, H = 64, 36
+    tracer.resize(W, H)
+    o = po.Oracle.from_scene(s, sky_small)
+    try:
+        for spp, maxb in ((1, 4), (5, 4), (16, 8)):
+            p = pa.make_params(s, W, H, spp=spp, max_bounces=maxb, seed=0.37)
+            want, ids, st = o.render(p, W, H, threads=4)
+            tracer.set_option("reuse_primary_hit", 1)
+            tracer.stats(); tracer.render(p)
+            got = tracer.read_result(); gst = tracer.stats()
+            _assert_same_image(got, want, f"reuse, {spp} spp")
+            assert (tracer.read_hit_ids() == ids).all()
+            assert gst["paths"] == st["paths"] == W * H * spp
+            assert gst["rays"] == st["rays"] - (st["paths"] - W * H)
+            tracer.set_option("reuse_primary_hit", 0)
+            tracer.stats(); tracer.render(p)
+            assert tracer.stats()["rays"] == st["rays"]
+    finally:
+        tracer.set_option("reuse_primary_hit", 0)

@@ -1,0 +1,16 @@
+"""Experiment: headline workload with and without reuse of the primary hit."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pathtracing_amd as pa
+scene = pa.Scene("hall260k"); sky = pa.procedural_sky(2048, 1024)
+W, H = 1920, 1080
+t = pa.PathTracer(0); t.load_scene(scene, sky); t.resize(W, H)
+for reuse in (0, 1, 0, 1):
+    t.set_option("reuse_primary_hit", reuse)
+    t.render(pa.make_params(scene, W, H, seed=0.1, spp=16, max_bounces=8)); t.sync(); t.stats()
+    t0 = time.perf_counter()
+    for k in range(5):
+        t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=16, max_bounces=8))
+    t.sync(); dt = (time.perf_counter() - t0) / 5
+    st = t.stats()
+    print("reuse", reuse, "ms/frame", round(dt * 1e3, 3), "rays/frame", st["rays"] // 5, "Mrays/s executed", round(st["rays"] / 5 / dt / 1e6, 1), flush=True)
