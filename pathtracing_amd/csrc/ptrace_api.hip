@@ -637,8 +637,8 @@ int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height)
 int pt_resize(pt_context *ctx, int width, int height)
 {
     if (!ctx) return PT_ERR_INVALID;
-    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 28)
-        return fail(ctx, PT_ERR_INVALID, "pt_resize: bad size");
+    if (width <= 0 || height <= 0 || width > 32767 || height > 32767 || (int64_t)width * height > (int64_t)1 << 28)
+        return fail(ctx, PT_ERR_INVALID, "pt_resize: bad size (1..32767 per side, at most 2^28 pixels)");
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool rebind_r = ctx->result == ctx->own_result, rebind_c = ctx->conv == ctx->own_conv,
