@@ -142,6 +142,45 @@ __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void taa_kernel(cons
     a.result[(size_t)y * a.W + x] = make_float4(aa.x, aa.y, aa.z, mixRate);                  // SH:713, SH:929
 }
 
+// ---- primary rays only: the _Depth == 1 dispatch (SH:799-809) and the primary-hit pass of renderMode 6 ----
+//
+// One pixel per thread and pass over the rectangle (8x8 pixel blocks, so a wave's rays are neighbours and walk
+// the tree almost in step); no path state, no regeneration, so none of the persistent kernel's machinery.
+// what == 1: Result = distance / 16 in all channels (+ hit ids); what == 2: t of the hit to a.seed_out,
+// rows skip_lo .. skip_hi (the stripe being path-traced) left out.
+template <int WIDE>
+__global__ __launch_bounds__(kBlock) void primary_kernel(const RenderArgs a, int what, int skip_lo, int skip_hi)
+{
+    __shared__ uint32_t lds_stack[kStackLds * kBlock];
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, n_threads = gridDim.x * kBlock;
+    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + tid, n_threads};
+    const int lane = threadIdx.x & 63;
+    uint32_t cn = 0, cp = 0, rays = 0;
+    // the grid is capped (the stack overflow area is per resident thread); a thread takes every n_threads-th pixel
+    for (uint32_t item = tid; item < a.total_items; item += n_threads) {
+        int x = 0, y = 0;
+        if (!item_pixel(a, item, x, y) || (what == 2 && y >= skip_lo && y <= skip_hi)) continue;
+        f3 o, d;
+        camera_ray(a, x, y, o, d);
+        float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
+        intersect_ground_plane(o, d, t, id);
+        traverse<WIDE>(a.sc, o, d, t, id, rec, st, cn, cp);
+        rays++;
+        const size_t p = (size_t)y * a.W + x;
+        if (what == 1) {
+            const float dis = t / 16.0f;                                  // SH:806-807
+            a.result[p] = make_float4(dis, dis, dis, dis);
+            if (a.hit_ids) a.hit_ids[p] = id;
+        } else {
+            a.seed_out[p] = t;
+        }
+    }
+    stats_add(a.stats, 0, rays, lane);
+    stats_add(a.stats, 1, cn, lane);
+    stats_add(a.stats, 2, cp, lane);
+    stats_add(a.stats, 3, rays, lane);
+}
+
 // ---- the display pass Assets/Shaders/Denoiser.shader (Graphics.Blit(_target, destination, denoiser),
 // RayTracingMaster.cs:760-764, when imageBlur is on) ----
 //

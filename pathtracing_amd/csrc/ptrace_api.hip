@@ -722,6 +722,24 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     return PT_OK;
 }
 
+// Primary rays only over the rectangle: what == 1 the _Depth dispatch, what == 2 t of the hits into d_seeds.
+static int launch_primary(pt_context *ctx, RenderArgs &a, int what, int x0, int y0, int tw, int th, int skip_lo, int skip_hi)
+{
+    if (tw <= 0 || th <= 0) return PT_OK;
+    int rc;
+    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th;
+    a.tiles_x = (tw + 7) / 8;
+    const int tiles_y = (th + 7) / 8;
+    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    const int grid = (int)std::min<int64_t>(((int64_t)a.total_items + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8 * 4);
+    if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
+    a.stack_overflow = ctx->d_stack_ovf;
+    if (ctx->bvh_width == 4) hipLaunchKernelGGL(primary_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
+    else hipLaunchKernelGGL(primary_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 // Scratch of the screen-space passes: one float4 and one float per pixel.
 static int ensure_screen_scratch(pt_context *ctx)
 {
@@ -826,9 +844,7 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         if (mode == 6) {
             // SH:757-759: the other pixels' current primary hits, traced by the path kernel with nothing after the first hit
             RenderArgs prim = a;
-            prim.depth = 2; prim.hit_ids = nullptr;
-            if ((rc = launch_path(ctx, prim, 0, 0, ctx->W, s_rows ? s_lo : ctx->H))) return rc;
-            if (s_rows && (rc = launch_path(ctx, prim, 0, s_hi + 1, ctx->W, ctx->H - s_hi - 1))) return rc;
+            if ((rc = launch_primary(ctx, prim, 2, 0, 0, ctx->W, ctx->H, s_rows ? s_lo : 1, s_rows ? s_hi : 0))) return rc;
         }
         StripeArgs sa;
         sa.cams = ctx->d_cams[ctx->cam_slot]; sa.t_primary = ctx->d_seeds; sa.divisions = p->divisions; sa.counter = p->counter; sa.mode = mode;
@@ -837,10 +853,13 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         PT_HIP(ctx, hipGetLastError());
         PT_HIP(ctx, hipEventRecord(ctx->ev_cams[ctx->cam_slot], ctx->stream));
         ctx->cams_used[ctx->cam_slot] = true;
-        if (s_rows && !no_samples && (rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
+        if (s_rows && a.depth == 1) { if ((rc = launch_primary(ctx, a, 1, 0, s_lo, ctx->W, s_rows, 1, 0))) return rc; }
+        else if (s_rows && !no_samples && (rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
         if (s_rows && p->depth != 1)   // SH:1108-1112, after every read of Result1 above
             PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)s_lo * ctx->W, pitch, ctx->result + (size_t)s_lo * ctx->W, pitch,
                                          (size_t)ctx->W * sizeof(float4), (size_t)s_rows, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (a.depth == 1) {
+        if ((rc = launch_primary(ctx, a, 1, x0, y0, tw, th, 1, 0))) return rc;
     } else {
         if ((rc = launch_path(ctx, a, x0, y0, tw, th))) return rc;
     }
