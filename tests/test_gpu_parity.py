@@ -702,3 +702,48 @@ def test_reuse_primary_hit_option(tracer, sky_small):
             assert tracer.stats()["rays"] == st["rays"]
     finally:
         tracer.set_option("reuse_primary_hit", 0)
+
+
+def test_master_mirror_partial_frame_mode_cycles_the_counter():
+    """The C++ RayTracingMaster mirror in renderMode 5 (RayTracingMaster.cs:513-526, 736-737): _Counter = counter++ %
+    divisions, the camera lists grow through a cycle and restart at its beginning, a shorter list leaves the tail of
+    the shader's arrays alone.  The oracle follows from the parameters the mirror uploads."""
+    import ctypes as C
+    from pathtracing_amd import _ffi
+    lib = _ffi.ptmaster()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        W, H, D = 64, 36, 4
+        assert lib.ptm_master_load_scene(h, s.handle, 128, 64) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, W, H, 1, 4, 0, pa.PT_ACCUM_NONE, 6)
+        lib.ptm_master_set_render_mode(h, 5)
+        lib.ptm_master_set_divisions(h, D)
+        orc = po.Oracle.from_scene(s, pa.procedural_sky(128, 64), accel=False)
+        ctx = lib.ptm_master_context(h)
+        res = np.zeros((H, W, 4), np.float32); res1 = np.zeros((H, W, 4), np.float32)
+        state = [pa.PtCameraHistory() for _ in range(100)]
+        old = []
+        counters = []
+        for k in range(2 * D + 1):
+            eye = (s.eye[0] + 0.1 * k, s.eye[1], s.eye[2] + 0.15 * k)
+            lib.ptm_master_set_camera(h, (C.c_float * 3)(*eye), (C.c_float * 3)(*s.target), C.c_float(s.fov), C.c_float(0.0))
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            counters.append(p.counter)
+            assert p.render_mode == 5 and p.divisions == D
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            state[:len(old)] = old
+            orc.render_history(p, state, W, H, res, res1, threads=4)
+            if p.counter == 0:
+                old = []
+            old.append(pa.camera_history_entry(eye, s.target, s.fov, W / H))
+            got = np.empty((H, W, 4), np.float32)
+            assert _ffi.ptrace().pt_read_result(ctx, got.ctypes.data) == 0
+            _assert_same_image(got, res, f"master stripes frame {k}")
+            assert _ffi.ptrace().pt_read_converged(ctx, got.ctypes.data) == 0
+            _assert_same_image(got, res1, f"master stripes history {k}")
+        assert counters == [0, 1, 2, 3, 0, 1, 2, 3, 0]
+    finally:
+        lib.ptm_master_destroy(h)

@@ -7,7 +7,7 @@ import pathtracing_amd as pa
 
 scene = pa.Scene("hall260k"); sky = pa.procedural_sky(2048, 1024)
 W, H = 1920, 1080
-def run(n_ctx, blocks, frames=12):
+def run(n_ctx, blocks, frames=24):
     trs = []
     for _ in range(n_ctx):
         t = pa.PathTracer(0); t.load_scene(scene, sky); t.resize(W, H); t.set_option("blocks_per_cu", blocks); trs.append(t)
@@ -22,5 +22,5 @@ def run(n_ctx, blocks, frames=12):
     rays = sum(t.stats()["rays"] for t in trs)
     for t in trs: t.close()
     return rays / dt / 1e6, dt / frames * 1e3
-for n, b in ((1, 0), (2, 0), (3, 0), (3, 3), (4, 2), (2, 2)):
+for n, b in ((3, 0), (4, 0), (6, 0), (4, 3)):
     print(n, b, run(n, b), flush=True)
