@@ -36,9 +36,12 @@ inline float box_area(const Aabb &b)
 }
 inline float centroid(const Aabb &b, int axis) { return 0.5f * (b.lo[axis] + b.hi[axis]); }
 
+// A primitive as the builder moves it around: its box travels with its index, so that every pass over a
+// range reads memory in order (an index array would make each pass a gather).
+struct Ref { Aabb box; uint32_t id; };
+
 struct Builder {
-    const std::vector<Aabb> &boxes;
-    std::vector<uint32_t> &order;
+    std::vector<Ref> refs;
     std::vector<Tmp> tmp;
     std::atomic<int32_t> next{0};
     std::atomic<int> live_threads{1};
@@ -48,8 +51,11 @@ struct Builder {
     float traversal_cost = 0.5f;   // cost of a node visit in units of one primitive test
     int max_threads;
 
-    Builder(const std::vector<Aabb> &b, std::vector<uint32_t> &o, int leaf, int thr)
-        : boxes(b), order(o), tmp(2 * b.size() + 1), leaf_size(leaf), max_threads(thr) {}
+    Builder(const std::vector<Aabb> &b, int leaf, int thr)
+        : refs(b.size()), tmp(2 * b.size() + 1), leaf_size(leaf), max_threads(thr)
+    {
+        for (size_t i = 0; i < b.size(); i++) { refs[i].box = b[i]; refs[i].id = (uint32_t)i; }
+    }
 
     static int levels_needed(uint32_t n, int leaf)
     {
@@ -66,7 +72,7 @@ struct Builder {
         Aabb box, cbox;
         box_reset(box); box_reset(cbox);
         for (uint32_t i = first; i < first + n; i++) {
-            const Aabb &b = boxes[order[i]];
+            const Aabb &b = refs[i].box;
             box_grow(box, b);
             for (int k = 0; k < 3; k++) {
                 float c = centroid(b, k);
@@ -87,18 +93,28 @@ struct Builder {
 
         if (!force_median) {
             float best_cost = kInf; int best_axis = -1, best_bin = -1;
+            // one pass over the range fills the bins of all three axes
+            Aabb bins[3][kBins]; uint32_t cnts[3][kBins];
+            float blo[3], bscale[3]; bool usable[3];
             for (int axis = 0; axis < 3; axis++) {
-                float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
-                if (!(ext > 0.0f)) continue;
-                float scale = (float)kBins / ext;
-                Aabb bb[kBins]; uint32_t cnt[kBins];
-                for (int b = 0; b < kBins; b++) { box_reset(bb[b]); cnt[b] = 0; }
-                for (uint32_t i = first; i < first + n; i++) {
-                    const Aabb &pb = boxes[order[i]];
-                    int b = (int)((centroid(pb, axis) - lo) * scale);
+                blo[axis] = cbox.lo[axis];
+                float ext = cbox.hi[axis] - blo[axis];
+                usable[axis] = ext > 0.0f;
+                bscale[axis] = usable[axis] ? (float)kBins / ext : 0.0f;
+                for (int b = 0; b < kBins; b++) { box_reset(bins[axis][b]); cnts[axis][b] = 0; }
+            }
+            for (uint32_t i = first; i < first + n; i++) {
+                const Aabb &pb = refs[i].box;
+                for (int axis = 0; axis < 3; axis++) {
+                    if (!usable[axis]) continue;
+                    int b = (int)((centroid(pb, axis) - blo[axis]) * bscale[axis]);
                     b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    box_grow(bb[b], pb); cnt[b]++;
+                    box_grow(bins[axis][b], pb); cnts[axis][b]++;
                 }
+            }
+            for (int axis = 0; axis < 3; axis++) {
+                if (!usable[axis]) continue;
+                const Aabb *bb = bins[axis]; const uint32_t *cnt = cnts[axis];
                 float right_area[kBins]; uint32_t right_cnt[kBins];
                 Aabb acc; box_reset(acc); uint32_t c = 0;
                 for (int b = kBins - 1; b > 0; b--) {
@@ -124,12 +140,12 @@ struct Builder {
             if (best_axis >= 0) {
                 float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - lo;
                 float scale = (float)kBins / ext;
-                auto it = std::partition(order.begin() + first, order.begin() + first + n, [&](uint32_t id) {
-                    int b = (int)((centroid(boxes[id], best_axis) - lo) * scale);
+                auto it = std::partition(refs.begin() + first, refs.begin() + first + n, [&](const Ref &rf) {
+                    int b = (int)((centroid(rf.box, best_axis) - lo) * scale);
                     b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
                     return b <= best_bin;
                 });
-                mid = (uint32_t)(it - order.begin());
+                mid = (uint32_t)(it - refs.begin());
                 split_done = mid > first && mid < first + n;
             }
         }
@@ -141,8 +157,8 @@ struct Builder {
                 if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
             mid = first + n / 2;
             if (cbox.hi[axis] > cbox.lo[axis])
-                std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + n,
-                                 [&](uint32_t a, uint32_t b) { return centroid(boxes[a], axis) < centroid(boxes[b], axis); });
+                std::nth_element(refs.begin() + first, refs.begin() + mid, refs.begin() + first + n,
+                                 [&](const Ref &a, const Ref &b) { return centroid(a.box, axis) < centroid(b.box, axis); });
         }
 
         uint32_t nl = mid - first, nr = n - nl;
@@ -173,13 +189,12 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
     if (n == 0) return out;
     leaf_size = std::max(1, std::min(leaf_size, kMaxLeafPrims));
     if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    out.order.resize(n);
-    for (uint32_t i = 0; i < n; i++) out.order[i] = i;
-
-    Builder b(boxes, out.order, leaf_size, threads);
+    Builder b(boxes, leaf_size, threads);
     b.traversal_cost = traversal_cost;
     int32_t root = b.build(0, n, 0);
     out.depth = b.max_depth.load();
+    out.order.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.order[i] = b.refs[i].id;
 
     // Emit the device layout in depth-first order: each inner node carries both children's boxes.
     const std::vector<Tmp> &tmp = b.tmp;
