@@ -163,7 +163,7 @@ struct Builder {
 
         uint32_t nl = mid - first, nr = n - nl;
         int32_t l, r;
-        bool spawn = nl > 32768 && nr > 32768 && live_threads.load() < max_threads;
+        bool spawn = nl > 2048 && nr > 2048 && live_threads.load() < max_threads;
         if (spawn) {
             live_threads.fetch_add(1);
             std::thread t([&] { l = build(first, nl, depth + 1); live_threads.fetch_sub(1); });

@@ -214,7 +214,9 @@ int rebuild_scene(pt_context *ctx)
     if (const char *env = std::getenv("PTRACE_LEAF")) leaf_size = std::max(1, std::min(4, std::atoi(env)));
     float ct = 1.0f;
     if (const char *env = std::getenv("PTRACE_SAH_CT")) ct = (float)std::atof(env);
+    auto t_prep = std::chrono::steady_clock::now();
     BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct);
+    auto t_built = std::chrono::steady_clock::now();
 
     std::vector<float4> recs(nP * 3);
     std::vector<uint32_t> by_id(nP);
@@ -308,6 +310,10 @@ int rebuild_scene(pt_context *ctx)
     ctx->stats.bvh_depth = ctx->bvh_width == 4 ? bvh.depth4 : bvh.depth;
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("PTRACE_BUILD_TIMING"))
+        std::fprintf(stderr, "scene build: prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n",
+                     std::chrono::duration<float, std::milli>(t_prep - t0).count(), std::chrono::duration<float, std::milli>(t_built - t_prep).count(),
+                     std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_built).count());
     ctx->scene_dirty = false;
     ctx->bvh2_stale = false;
     return PT_OK;
