@@ -54,7 +54,6 @@ struct RenderArgs {
     uint32_t shard_items;         // a multiple of 64 (whole 8x8 pixel blocks)
     int32_t n_shards;             // 1 .. kWorkShards counters in use
     uint32_t *stack_overflow;     // kStackOverflow * (threads in the grid) entries
-    float4 *lane_state;           // path_sched_kernel: 4 float4 per thread of the grid
     unsigned long long *stats;    // [0] rays [1] nodes [2] prims [3] paths
     // wavefront pipeline state, one slot per work item (pt_wavefront.hpp)
     float4 *ray_o;                // (origin.xyz, _Seed)
@@ -700,25 +699,26 @@ constexpr int kIdleNode = (int)0x80000001;   // no pixel yet / pixel finished: w
 constexpr int kDeadNode = (int)0x80000002;   // no pixel and none left
 __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && node > kDeadNode; }
 
-// Per-lane path state lives in global memory between shade phases (one slot per thread of the grid,
-// struct-of-arrays, so a wave's accesses coalesce); only what traversal needs stays in registers.
-// That keeps the register count of the traversal phases, and with it the kernel's occupancy, down.
+// Per-lane path state lives in LDS between shade phases ([slot][thread] float4, conflict-free); only what
+// traversal needs stays in registers.  That keeps the register count of the traversal phases, and with it the
+// kernel's occupancy, down, and costs no memory traffic.
 //   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, t of the primary hit)
 //   ls2 = (pixel x | y << 16, sample | bounce << 20, primary record, primary id)   ls3 = (rays, nodes, prims, paths) counters
 template <int WIDE, bool MAT>
 __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 {
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
-    __shared__ float lds_save[9 * kBlock];   // traversal-only registers parked here during a shade phase
+    __shared__ float lds_save[3 * kBlock];   // node, sp, ray_work parked here during a shade phase
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x, n_threads = gridDim.x * kBlock;
     const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads};
     const int lane = threadIdx.x & 63;
     const SceneDev &sc = a.sc;
-    float4 *const lsb = a.lane_state + gtid;   // slot k of this thread at lsb[k * n_threads]
+    __shared__ float4 lds_state[4 * kBlock];   // ls0 .. ls3 of every thread, [slot][thread]
+    float4 *const lsb = lds_state + threadIdx.x;
 #define ls0 (lsb)
-#define ls1 (lsb + n_threads)
-#define ls2 (reinterpret_cast<int4 *>(lsb + 2 * (size_t)n_threads))
-#define ls3 (reinterpret_cast<int4 *>(lsb + 3 * (size_t)n_threads))
+#define ls1 (lsb + kBlock)
+#define ls2 (reinterpret_cast<int4 *>(lsb + 2 * kBlock))
+#define ls3 (reinterpret_cast<int4 *>(lsb + 3 * kBlock))
 
     f3 o = pt_make3(0, 0, 0), d = pt_make3(0, 0, 1);
     RaySlabs rsl = {0, 0, 0, 0, 0, 0};
@@ -750,9 +750,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // LDS so that the shading code has those registers (the compiler cannot know they are idle).
             {
                 float *sv = lds_save + threadIdx.x;
-                sv[0 * kBlock] = rsl.ix; sv[1 * kBlock] = rsl.iy; sv[2 * kBlock] = rsl.iz;
-                sv[3 * kBlock] = rsl.ox; sv[4 * kBlock] = rsl.oy; sv[5 * kBlock] = rsl.oz;
-                sv[6 * kBlock] = as_f(node); sv[7 * kBlock] = as_f(sp); sv[8 * kBlock] = as_f((int32_t)ray_work);
+                sv[0 * kBlock] = as_f(node); sv[1 * kBlock] = as_f(sp); sv[2 * kBlock] = as_f((int32_t)ray_work);
             }
             const bool was_done = node == kDoneNode, was_idle = node == kIdleNode;
             bool new_ray = false, finished = false, no_more = false;
@@ -766,7 +764,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                 int sample = px.y & 0xfffff, bounce = (int)((uint32_t)px.y >> 20), primary_id = px.w;
                 uint32_t primary_rec = (uint32_t)px.z;
                 {
-                    const uint32_t rw = (uint32_t)as_i(lds_save[threadIdx.x + 8 * kBlock]);
+                    const uint32_t rw = (uint32_t)as_i(lds_save[threadIdx.x + 2 * kBlock]);
                     cnt.y += (int)(rw & 0xffffu); cnt.z += (int)(rw >> 16);
                 }
                 if (a.depth == 1) {                                   // SH:799-809
@@ -875,16 +873,13 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // ---- set up traversal of the new rays (SH:262-269: plane first)
             {
                 const float *sv = lds_save + threadIdx.x;
-                rsl.ix = sv[0 * kBlock]; rsl.iy = sv[1 * kBlock]; rsl.iz = sv[2 * kBlock];
-                rsl.ox = sv[3 * kBlock]; rsl.oy = sv[4 * kBlock]; rsl.oz = sv[5 * kBlock];
-                node = as_i(sv[6 * kBlock]); sp = as_i(sv[7 * kBlock]); ray_work = (uint32_t)as_i(sv[8 * kBlock]);
+                node = as_i(sv[0 * kBlock]); sp = as_i(sv[1 * kBlock]); ray_work = (uint32_t)as_i(sv[2 * kBlock]);
             }
             if (no_more) node = kDeadNode;
             else if (finished && !new_ray) node = kIdleNode;   // pixel done, its replacement lay outside the tile
             if (new_ray) {
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
-                rsl = ray_slabs(o, d);
                 sp = 0;
                 node = sc.n_nodes ? 0 : kDoneNode;
                 ray_work = 0;
@@ -895,6 +890,9 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     cnt.x--;
                 }
             }
+            // The slab constants are not kept across the shade phase: every lane computes them here, the lanes that kept
+            // their ray getting the values they had (the wave runs this code for the new rays anyway).
+            rsl = ray_slabs(o, d);
             if (waiting) *ls3 = cnt;
             continue;
         }

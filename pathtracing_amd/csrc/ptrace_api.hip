@@ -77,7 +77,6 @@ struct pt_context {
     int32_t *ids = nullptr;
 
     uint32_t *d_work = nullptr;
-    float4 *d_lane_state = nullptr;    // path_sched_kernel's per-thread path state
     uint32_t *d_stack_ovf = nullptr;   // traversal stack overflow, kStackOverflow entries per thread
     size_t stack_ovf_threads = 0;
     unsigned long long *d_stats = nullptr;
@@ -352,8 +351,6 @@ int ensure_stack_overflow(pt_context *ctx, size_t threads)
     free_dev(ctx->d_stack_ovf);
     ctx->stack_ovf_threads = 0;
     PT_HIP(ctx, hipMalloc((void **)&ctx->d_stack_ovf, threads * kStackOverflow * sizeof(uint32_t)));
-    free_dev(ctx->d_lane_state);
-    PT_HIP(ctx, hipMalloc((void **)&ctx->d_lane_state, threads * 4 * sizeof(float4)));
     ctx->stack_ovf_threads = threads;
     return PT_OK;
 }
@@ -507,7 +504,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds); free_dev(ctx->own_display);
-    free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf); free_dev(ctx->d_lane_state);
+    free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
     for (int i = 0; i < pt_context::kCamRing; i++) {
@@ -715,7 +712,6 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * per_cu);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
-    a.lane_state = ctx->d_lane_state;
     a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
     if (ctx->d_mesh_mat) {
         if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
