@@ -335,6 +335,7 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
             if mode != 1:
                 t.set_camera_history([hist_entry[k - 1]] if k else [])
             t.render(prm[k])
+        t.clear_camera_history()
         for k in range(3):
             frame(k)
         t.sync()
@@ -356,7 +357,7 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
             if k % divisions == 0:
                 old = []
             old.append(hist_entry[k])
-        t.set_camera_history([])
+        t.clear_camera_history()
         for k in range(divisions):
             frame(k)
         t.sync()

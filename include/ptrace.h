@@ -1,9 +1,10 @@
 /*
  * ptrace.h - C ABI of libptrace: the path-tracing compute kernel of
  * VirtualEngineeringLab/Pathtracing (Assets/Scripts/RayTracingShader.compute,
- * kernel CSMain: plain path-trace mode, renderMode 1; depth-aware temporal
- * reprojection, renderMode 2; reprojection + a-trous denoiser + temporal
- * anti-aliasing, renderMode 0) plus progressive accumulation
+ * kernel CSMain in every renderMode the host can select: plain path tracing,
+ * depth-aware temporal reprojection and its blur / headset / partial-frame /
+ * full-frame / pause variants, reprojection + a-trous denoiser + temporal
+ * anti-aliasing) plus progressive accumulation
  * (Assets/Shaders/AddMat.shader), implemented as HIP kernels for gfx950.
  *
  * Each entry point replaces one call the reference's C# host
@@ -104,9 +105,11 @@ typedef struct PtFrameParams {
     int32_t max_bounces;                 /* path segments per sample; the shader hard-codes 4
                                             (RayTracingShader.compute:866-873); 1..4095          */
     int32_t depth;                       /* _Depth                    RayTracingMaster.cs:532     */
-    int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735,977-990): 1 = Default,
-                                            2 = Reproj, 0 = Denoise, 5 = PartialFrameReproj,
-                                            6 = PartialFrameReprojDepth; the others are PT_ERR_UNSUPPORTED */
+    int32_t render_mode;                 /* renderMode (RayTracingMaster.cs:735,977-990): 0 = Denoise, 1 = Default,
+                                            2 = Reproj, 3 = BlurAndReproj, 4 = StereoReproj, 5 = PartialFrameReproj,
+                                            6 = PartialFrameReprojDepth, 7 = FullFrameReproj, 8 = FullFrameReprojDepth,
+                                            10 = NewRender, 11 = PlanerPause, 12 = DepthPause; anything else is
+                                            PT_ERR_UNSUPPORTED */
     uint32_t sample_index;               /* _Sample of AddMat.shader:42 (RayTracingMaster.cs:805) */
     int32_t accumulate;                  /* PT_ACCUM_*                                            */
     int32_t tile_x0, tile_y0;            /* sub-rectangle of the image this dispatch renders;     */
@@ -115,7 +118,8 @@ typedef struct PtFrameParams {
     float directional_light[4];          /* _DirectionalLight uploaded, unused (RayTracingShader.compute:19)    */
     int32_t accumulation_frames;         /* _AccumulationFrames (RayTracingMaster.cs:738); renderMode 0 and 2   */
     int32_t divisions;                   /* _Divisions (RayTracingMaster.cs:736) and                            */
-    int32_t counter;                     /* _Counter = counter++ % divisions (:737); renderMode 5 and 6 only    */
+    int32_t counter;                     /* _Counter = counter++ % divisions (:737); renderMode 5 .. 8 only     */
+    int32_t left_eye;                    /* _leftEye (RayTracingMaster.cs:462); renderMode 4 only               */
 } PtFrameParams;
 
 /* One element of each of the four history arrays _CameraToWorldOld,
@@ -205,9 +209,11 @@ int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height);
  * "_CameraProjectionOld") (RayTracingMaster.cs:468-471,492-495): the cameras of earlier frames,
  * entry 0 first.  Like a write into the shader's uniform arrays, a call overwrites elements
  * 0..count-1 and leaves the others as they were (the partial-frame modes rely on that: early in a
- * cycle the tail still holds the previous cycle's cameras).  All elements start as zero matrices -
- * renderMode 2 then finds no valid reprojection and writes the fresh frame, as on the reference's
- * first frame - and count == 0 puts them back to that state.  count 0..PT_MAX_CAMERA_HISTORY. */
+ * cycle the tail still holds the previous cycle's cameras; the pause modes, whose host list is
+ * empty, rely on count == 0 changing nothing).  All elements start as zero matrices - renderMode 2
+ * then finds no valid reprojection and writes the fresh frame, as on the reference's first frame.
+ * entries == NULL with count == PT_MAX_CAMERA_HISTORY puts every element back to zero (no counterpart
+ * in the reference).  count 0..PT_MAX_CAMERA_HISTORY. */
 int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int count);
 
 /* InitRenderTexture (RayTracingMaster.cs:542-583): allocate Result / converged
@@ -245,7 +251,30 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
  * the camera that rendered ITS stripe (history element divisions - y/s - 1) saw the point 10 units along
  * the pixel's current camera ray (mode 5) or the pixel's current primary hit (mode 6; a primary miss
  * shows the sky), or (0,0,0,1) when that position is off screen.  Result1 is read as it was before the
- * dispatch.  Whole frames only; accumulate must be PT_ACCUM_NONE. */
+ * dispatch.  Whole frames only; accumulate must be PT_ACCUM_NONE.
+ *
+ * renderMode 3 (:986-1019) and 4 (:1021-1046) are renderMode 2 with another blend: 3 mixes the fresh radiance
+ * (1/2.5) with the bilinear history sample (1/5) and the history's four diagonal neighbours (1/10 each) and
+ * tests the distance against the unfiltered texel; 4 finds the old position with FindCameraRayVR (:418-437:
+ * the headset's 2240/2016 aspect ratio and per-eye pixel offsets, `left_eye`).
+ *
+ * renderMode 10 (:1048-1069): a pixel whose primary hit is found in the history (on screen, distance within
+ * 5 % or beyond 80) shows the bilinear history sample, alpha included, and traces no path; every other pixel
+ * is path-traced as in renderMode 1.  The host sets samples_per_pixel to 1 from this mode on
+ * (RayTracingMaster.cs:531).
+ *
+ * renderMode 11 / 12 (:1071-1104; "pause"): no path is traced and Result1 is left alone; every pixel shows
+ * the bilinear sample of Result1 where history camera 0 saw the point 10 units along the pixel's ray (11) or
+ * the pixel's primary hit (12; a miss gives (0,0,0,1), as does a position off screen).  Whole frames only.
+ *
+ * renderMode 7 / 8 (:751-789,850-853,938-948): like 5 / 6 the frame is rendered one stripe per dispatch, but
+ * into Result2 and from a history camera - element counter-1, the previous dispatch's camera - while EVERY
+ * pixel of Result shows Result1 reprojected from history camera 0 (the camera of the cycle's first dispatch)
+ * through the point 10 units along its ray (7) or its primary hit (8; a miss shows the sky and, in the
+ * stripe, is not path-traced).  The dispatch with counter 0 path-traces the whole frame and then copies
+ * Result2 into Result1 and Result.  Its camera index, (0-1) % divisions = -1, addresses the uniform declared
+ * just before each array (:8-11): the current camera.  History rays are built by CreateCameraRayOld
+ * (:374-387: clip z = 1).  Whole frames only. */
 int pt_render(pt_context *ctx, const PtFrameParams *params);
 
 /* Graphics.Blit(_target, destination, denoiser) (RayTracingMaster.cs:760-764, the imageBlur switch):

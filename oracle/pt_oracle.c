@@ -635,44 +635,92 @@ static void taa(const float *result1, const float *cur, int W, int H, float fx, 
     out4[0] = antialiased.x; out4[1] = antialiased.y; out4[2] = antialiased.z; out4[3] = mixRate;   /* SH:713 */
 }
 
-/* CSMain for one thread id, renderMode 1 or 2: SH:798-809, SH:822-874, SH:933-936, SH:950-983.
- * The prologue copy Result1 = Result (SH:728-731) is done for the whole rectangle by the caller
- * before any pixel runs; `hs` is NULL in renderMode 1. */
-static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, int idx, int idy,
-                    float *out4, int32_t *hit_id, Counters *cn, const History *hs, float *seed_out)
+/* SH:374-387 CreateCameraRayOld(uv, framesBack): as CreateCameraRay but against element framesBack of the history
+ * arrays and with clip-space z = 1 (SH:381) instead of 0 (SH:115).  mul(M, float4(u, v, 1, 1)) is taken in the order
+ * ((M0*u + M1*v) + M2) + M3. */
+static Ray create_camera_ray_old(const float *c2w, const float *ip, float u, float v)
 {
+    f3 origin = pt_make3(c2w[12], c2w[13], c2w[14]);
+    f3 d;
+    d.x = (pt_fma(ip[4], v, ip[0] * u) + ip[8]) + ip[12];
+    d.y = (pt_fma(ip[5], v, ip[1] * u) + ip[9]) + ip[13];
+    d.z = (pt_fma(ip[6], v, ip[2] * u) + ip[10]) + ip[14];
+    d = pt_mul_dir(c2w, d);
+    d = pt_normalize3(d);
+    return create_ray(origin, d);
+}
+
+/* SH:418-437 FindCameraRayVR(input): the headset variant of FindCameraRay with the eye texture's aspect ratio and
+ * per-eye pixel offsets hard-coded; history element 0. */
+static void find_camera_ray_vr(const History *hs, int H, f3 direction, int left_eye, float *uv_out)
+{
+    const float *P = hs->cam->camera_projection;
+    float m11 = P[1 * 4 + 1], m22 = P[2 * 4 + 2], m23 = P[3 * 4 + 2];
+    float nearp = -m23 / m22;                                            /* SH:425 */
+    float farp = -(nearp * m22) / (1.0f - m22);                          /* SH:426 */
+    f3 pos = pt_scale3(pt_normalize3(direction), nearp + (farp - nearp)); /* SH:427 */
+    float ratio = 2240.0f / 2016.0f;                                     /* SH:428 */
+    f3 toCam = pt_mul_dir(hs->cam->world_to_camera, pos);                /* SH:430 */
+    float camPosZ = toCam.z;
+    float height = camPosZ / m11;                                        /* SH:432 */
+    float width = ratio * height;                                        /* SH:433 */
+    float uvx = (toCam.x - width * (2240.0f / 2016.0f)) / width;         /* SH:434 */
+    float uvy = (toCam.y - height) / height;                             /* SH:435 */
+    float ph = (float)(uint32_t)H;
+    uv_out[0] = (1.0f - uvx * (ph * ratio / 2.043f)) - (left_eye ? 156.0f : 538.0f);   /* SH:436 */
+    uv_out[1] = (1.0f - uvy * (ph / 2.0f)) - (left_eye ? -1.3f : -0.6f);
+}
+
+/* CSMain for one thread id (SH:725-1112), every renderMode of RayTracingMaster.cs:977-990.
+ * The prologue copies Result1 = Result / Result2 (SH:728-736) are done for the whole rectangle by the caller
+ * before any pixel runs, and so are the copies that end a dispatch (SH:944-947, SH:1108-1112): the return value
+ * is 1 for a thread that reaches the end of the sample loop, which is the thread those copies belong to.
+ * out4 = Result[id], out2 = Result2[id] (renderMode 7 / 8; NULL otherwise); `hs` carries the history arrays and
+ * Result1 as it was before the dispatch (NULL in renderMode 1). */
+static int cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, int idx, int idy,
+                   float *out4, float *out2, int32_t *hit_id, Counters *cn, const History *hs, float *seed_out)
+{
+    const int mode = prm->render_mode;
     float fw = (float)W, fh = (float)H;
     float u = (float)idx / fw * 2.0f - 1.0f;   /* SH:802, SH:842: pixel corner, no jitter */
     float v = (float)idy / fh * 2.0f - 1.0f;
-    if (prm->render_mode == 5 || prm->render_mode == 6) {   /* SH:742-789: pixels outside the stripe being rendered */
-        float stripe = fh / (float)prm->divisions;                                   /* SH:742 */
-        float fy = (float)idy;
-        if (fy > fh - stripe * (float)prm->counter || fy < fh - stripe * (float)(prm->counter + 1)) {   /* SH:751 */
-            Ray rayr = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);   /* SH:753-754 */
-            f3 hitPosr = pt_along3(rayr.origin, 10.0f, rayr.direction);              /* SH:755 */
-            if (prm->render_mode % 2 == 0) {                                         /* SH:757-764 */
-                RayHit hitr = trace(p, &rayr, cn);
-                cn->rays++; cn->paths++;
-                hitPosr = hitr.position;
-                if (!(hitr.distance < PT_INF)) {
-                    f3 sky = skybox_sample(p, &rayr);
-                    out4[0] = sky.x; out4[1] = sky.y; out4[2] = sky.z; out4[3] = 1.0f;
-                    return;
-                }
+    float fy = (float)idy;
+    float stripe = 0.0f;
+    int outside = 0, inside_or_edge = 1;
+    if (mode >= 5 && mode <= 8) {
+        stripe = fh / (float)prm->divisions;                                         /* SH:742 */
+        outside = fy > fh - stripe * (float)prm->counter || fy < fh - stripe * (float)(prm->counter + 1);        /* SH:751, SH:786 */
+        inside_or_edge = fy <= fh - stripe * (float)prm->counter || fy >= fh - stripe * (float)(prm->counter + 1); /* SH:853, SH:939 */
+    }
+    if (((mode == 5 || mode == 6) && outside) || mode == 7 || mode == 8) {           /* SH:751-789 */
+        Ray rayr = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);   /* SH:753-754 */
+        f3 hitPosr = pt_along3(rayr.origin, 10.0f, rayr.direction);                  /* SH:755 */
+        if (mode % 2 == 0) {                                                         /* SH:757-764 */
+            RayHit hitr = trace(p, &rayr, cn);
+            cn->rays++; cn->paths++;
+            hitPosr = hitr.position;
+            if (!(hitr.distance < PT_INF)) {
+                f3 sky = skybox_sample(p, &rayr);
+                out4[0] = sky.x; out4[1] = sky.y; out4[2] = sky.z; out4[3] = 1.0f;
+                return 0;
             }
+        }
+        int framesBack = 0;
+        if (mode == 5 || mode == 6) {
             /* SH:766: (_Divisions - (id.y / stripe)) - 1 % _Divisions, a float, truncated into the int */
-            int framesBack = (int)(((float)prm->divisions - fy / stripe) - (float)(1 % prm->divisions));
+            framesBack = (int)(((float)prm->divisions - fy / stripe) - (float)(1 % prm->divisions));
             if (framesBack < 0) framesBack = 0;                                      /* keep the index inside the arrays */
             if (framesBack > PT_MAX_CAMERA_HISTORY - 1) framesBack = PT_MAX_CAMERA_HISTORY - 1;
-            History h = {&hs->all[framesBack], hs->result1, hs->all};
-            f3 originOld = pt_make3(h.cam->camera_to_world[12], h.cam->camera_to_world[13], h.cam->camera_to_world[14]);   /* SH:769 */
-            float reproUV[2];
-            find_camera_ray(&h, W, H, pt_sub3(hitPosr, originOld), reproUV);         /* SH:770 */
-            if (reproUV[0] < fw && reproUV[0] > 0 && reproUV[1] < fh && reproUV[1] > 0)
-                bilinear_texture_sample(&h, W, H, reproUV[0], reproUV[1], out4);     /* SH:776 */
-            else { out4[0] = out4[1] = out4[2] = 0.0f; out4[3] = 1.0f; }             /* SH:780 */
-            return;                                                                  /* SH:783-784 */
         }
+        History h = {&hs->all[framesBack], hs->result1, hs->all};
+        f3 originOld = pt_make3(h.cam->camera_to_world[12], h.cam->camera_to_world[13], h.cam->camera_to_world[14]);   /* SH:769 */
+        float reproUV[2];
+        find_camera_ray(&h, W, H, pt_sub3(hitPosr, originOld), reproUV);             /* SH:770 */
+        if (reproUV[0] < fw && reproUV[0] > 0 && reproUV[1] < fh && reproUV[1] > 0)
+            bilinear_texture_sample(&h, W, H, reproUV[0], reproUV[1], out4);         /* SH:776 */
+        else { out4[0] = out4[1] = out4[2] = 0.0f; out4[3] = 1.0f; }                 /* SH:780 */
+        if (mode <= 6) return 0;                                                     /* SH:783-784 */
+        if (prm->counter % prm->divisions != 0 && outside) return 0;                 /* SH:786-788 */
     }
     if (prm->depth == 1) {                     /* SH:799-809 */
         Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
@@ -681,7 +729,7 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
         float dis = hit.distance / 16.0f;
         out4[0] = out4[1] = out4[2] = out4[3] = dis;
         if (hit_id) *hit_id = hit.id;
-        return;
+        return 0;
     }
     f3 result = pt_make3(0, 0, 0);
     RngState rs; rs.seed = prm->seed; rs.px = (float)idx * 2.0f; rs.py = (float)idy * 2.0f; /* SH:831 */
@@ -689,45 +737,73 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
     float fspp = (float)spp;
     int maxb = prm->max_bounces;
     f3 camo = pt_make3(prm->camera_to_world[12], prm->camera_to_world[13], prm->camera_to_world[14]);
-    if (prm->render_mode == 1) out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; /* spp <= 0: the shader writes nothing; targets start zeroed */
+    if (mode == 1) out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; /* spp <= 0: the shader writes nothing; targets start zeroed */
     for (int j = 1; j < spp + 1; j++) {            /* SH:839 */
-        Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);
-        cn->paths++;
-        RayHit hit = trace_logged(p, &ray, cn);    /* SH:859 */
-        cn->rays++;
-        f3 hitPos = hit.position;                  /* SH:860; (0,0,0) on a miss */
-        if (hit_id) *hit_id = hit.id;
-        int primary_miss = !(hit.distance < PT_INF);
-        {   /* SH:866: energy is read before Shade() changes it */
-            f3 e = ray.energy;
-            f3 s = shade(p, &rs, &ray, hit);
-            result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+        Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);   /* SH:848 */
+        if (mode == 7 || mode == 8) {              /* SH:850-852 */
+            /* (_Counter - 1) % _Divisions is -1 when _Counter is 0.  Element -1 of a uniform array is the uniform
+             * declared just before it - the constant buffer is contiguous and SH:8-11 declare _CameraToWorld before
+             * _CameraToWorldOld[100] and _CameraInverseProjection before _CameraInverseProjectionOld[100] - so that
+             * dispatch renders from the current camera (through CreateCameraRayOld's z = 1). */
+            int fb = (prm->counter - 1) % prm->divisions;
+            if (fb < 0) ray = create_camera_ray_old(prm->camera_to_world, prm->camera_inverse_projection, u, v);
+            else ray = create_camera_ray_old(hs->all[fb].camera_to_world, hs->all[fb].camera_inverse_projection, u, v);
         }
-        for (int i = 1; i < maxb; i++) {           /* SH:867 (4 in the shader) */
+        int fullFrameReprojRender = (mode != 7 && mode != 8) || inside_or_edge;      /* SH:853 */
+        cn->paths++;
+        f3 hitPos = pt_along3(ray.origin, 10.0f, ray.direction);                     /* SH:855 */
+        int skyboxS = 0;                           /* SH:856 */
+        RayHit hit = create_ray_hit();             /* SH:857 leaves it unset; it is not read before SH:859 sets it */
+        if (mode != 11 && fullFrameReprojRender) { /* SH:858-863 */
             hit = trace_logged(p, &ray, cn);
-            if (!(i == 1 && primary_miss)) cn->rays++;
-            f3 e = ray.energy;
-            f3 s = shade(p, &rs, &ray, hit);
-            result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
-            if (!any3(ray.energy)) break;          /* SH:871 */
+            cn->rays++;
+            hitPos = hit.position;                 /* (0,0,0) on a miss */
+            skyboxS = !(hit.distance < PT_INF);
+            if (hit_id) *hit_id = hit.id;
+        }
+        if (mode < 10 && fullFrameReprojRender) {  /* SH:865-874 */
+            {   /* SH:866: energy is read before Shade() changes it */
+                f3 e = ray.energy;
+                f3 s = shade(p, &rs, &ray, hit);
+                result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+            }
+            for (int i = 1; i < maxb; i++) {       /* SH:867 (4 in the shader) */
+                hit = trace_logged(p, &ray, cn);
+                if (!(i == 1 && skyboxS)) cn->rays++;
+                f3 e = ray.energy;
+                f3 s = shade(p, &rs, &ray, hit);
+                result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+                if (!any3(ray.energy)) break;      /* SH:871 */
+            }
         }
         if (seed_out) *seed_out = rs.seed;         /* _Seed as the denoiser's hash will see it (SH:564) */
-        if ((prm->render_mode == 2 || prm->render_mode == 0) && hs) {   /* SH:950-983; SH:885-925 writes Result2 the same way */
-            f3 origin = camo;
-            f3 originOld = pt_make3(hs->cam->camera_to_world[12], hs->cam->camera_to_world[13], hs->cam->camera_to_world[14]);
-            float reproUV[2];
-            find_camera_ray(hs, W, H, pt_sub3(hitPos, originOld), reproUV);
+        f3 origin = camo;
+        const float alphaNew = pt_length3(pt_sub3(hitPos, origin));
+        if (mode == 1 || mode == 5 || mode == 6 || !hs) {   /* SH:933-936 */
+            out4[0] = result.x; out4[1] = result.y; out4[2] = result.z; out4[3] = alphaNew;
+            continue;
+        }
+        if (mode == 7 || mode == 8) {              /* SH:938-948; the copies of :944-947 are the caller's */
+            if (inside_or_edge) { out2[0] = result.x; out2[1] = result.y; out2[2] = result.z; out2[3] = alphaNew; }
+            continue;
+        }
+        /* every other mode looks the primary hit up in the previous frame: history element 0 */
+        f3 originOld = pt_make3(hs->cam->camera_to_world[12], hs->cam->camera_to_world[13], hs->cam->camera_to_world[14]);
+        f3 toHit = pt_sub3(hitPos, originOld);
+        float distOld = pt_length3(toHit);
+        float reproUV[2];
+        if (mode == 4) find_camera_ray_vr(hs, H, toHit, prm->left_eye, reproUV);     /* SH:1026 */
+        else find_camera_ray(hs, W, H, toHit, reproUV);                              /* SH:890, 955, 991, 1051, 1074 */
+        const int on_screen = reproUV[0] < fw && reproUV[0] > 0 && reproUV[1] < fh && reproUV[1] > 0;
+        float bl[4] = {0, 0, 0, 0}, direct[4] = {0, 0, 0, 0};
+        if (on_screen) {
+            bilinear_texture_sample(hs, W, H, reproUV[0], reproUV[1], bl);
+            load_result1(hs, W, H, reproUV[0], reproUV[1], direct);
+        }
+        if (mode == 2 || mode == 0) {              /* SH:950-983; SH:885-925 writes Result2 the same way */
             float divisor = (float)prm->accumulation_frames;
-            int take = 0;
-            float bl[4] = {0, 0, 0, 0};
-            float distOld = pt_length3(pt_sub3(hitPos, originOld));
-            if (reproUV[0] < (float)W && reproUV[0] > 0 && reproUV[1] < (float)H && reproUV[1] > 0) {
-                float direct[4];
-                bilinear_texture_sample(hs, W, H, reproUV[0], reproUV[1], bl);
-                load_result1(hs, W, H, reproUV[0], reproUV[1], direct);
-                take = (pt_abs(distOld - bl[3]) < distOld * 0.05f || direct[3] > 80.0f) && !primary_miss;
-            }
-            if (take && prm->render_mode == 0) {   /* SH:908-915: history only from rows above the end of this thread group */
+            int take = on_screen && (pt_abs(distOld - bl[3]) < distOld * 0.05f || direct[3] > 80.0f) && !skyboxS;
+            if (take && mode == 0) {               /* SH:908-915: history only from rows above the end of this thread group */
                 float maximum = pt_floor((float)idy / 32.0f) * 32.0f + 32.0f;
                 if (!(reproUV[1] < maximum)) take = 0;
             }
@@ -737,15 +813,65 @@ static void cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H
                 out4[2] = (bl[2] * (divisor - 1.0f)) / divisor + result.z / divisor;
                 out4[3] = distOld;
             } else {                               /* SH:981, SH:914, SH:924 */
-                out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
-                out4[3] = pt_length3(pt_sub3(hitPos, origin));
+                out4[0] = result.x; out4[1] = result.y; out4[2] = result.z; out4[3] = alphaNew;
             }
-        } else {
-            /* SH:933-936 */
-            out4[0] = result.x; out4[1] = result.y; out4[2] = result.z;
-            out4[3] = pt_length3(pt_sub3(hitPos, camo));
+        } else if (mode == 3) {                    /* SH:986-1019: the history's texel and its four diagonal neighbours */
+            int take = on_screen && (pt_abs(distOld - direct[3]) < distOld * 0.05f || direct[3] > 80.0f) && !skyboxS;   /* SH:995-997 */
+            if (take) {
+                float divisor = 10.0f;
+                float n0[4], n1[4], n2[4], n3[4];
+                load_result1(hs, W, H, reproUV[0] + 1.0f, reproUV[1] + 1.0f, n0);    /* SH:1000 */
+                load_result1(hs, W, H, reproUV[0] - 1.0f, reproUV[1] - 1.0f, n1);    /* SH:1001 */
+                load_result1(hs, W, H, reproUV[0] + 1.0f, reproUV[1] + -1.0f, n2);   /* SH:1002 */
+                load_result1(hs, W, H, reproUV[0] - 1.0f, reproUV[1] - -1.0f, n3);   /* SH:1003 */
+                const float r3[3] = {result.x, result.y, result.z};
+                for (int k = 0; k < 3; k++) {
+                    float avg = r3[k] / 2.5f;      /* SH:998 */
+                    avg += bl[k] / 5.0f;           /* SH:999 */
+                    avg += n0[k] / divisor; avg += n1[k] / divisor; avg += n2[k] / divisor; avg += n3[k] / divisor;
+                    out4[k] = avg;
+                }
+                out4[3] = alphaNew;                /* SH:1005 */
+            } else {                               /* SH:1011 */
+                out4[0] = result.x; out4[1] = result.y; out4[2] = result.z; out4[3] = alphaNew;
+            }
+        } else if (mode == 4) {                    /* SH:1021-1046 */
+            float divisor = (float)prm->accumulation_frames;
+            int take = on_screen && (pt_abs(distOld - direct[3]) < distOld * 0.05f || bl[3] > 80.0f) && !skyboxS;   /* SH:1033-1035 */
+            if (take) {                            /* SH:1037 */
+                out4[0] = (bl[0] * (divisor - 1.0f)) / divisor + result.x / divisor;
+                out4[1] = (bl[1] * (divisor - 1.0f)) / divisor + result.y / divisor;
+                out4[2] = (bl[2] * (divisor - 1.0f)) / divisor + result.z / divisor;
+                out4[3] = distOld;
+            } else {                               /* SH:1043 */
+                out4[0] = result.x; out4[1] = result.y; out4[2] = result.z; out4[3] = alphaNew;
+            }
+        } else if (mode == 10) {                   /* SH:1048-1069: trace a path only where the history has nothing to show */
+            int take = on_screen && (pt_abs(distOld - bl[3]) < distOld * 0.05f || bl[3] > 80.0f) && !skyboxS;   /* SH:1053-1055 */
+            if (take) {
+                for (int k = 0; k < 4; k++) out4[k] = bl[k];                         /* SH:1056 */
+            } else {                               /* SH:1059-1067 */
+                {
+                    f3 e = ray.energy;
+                    f3 s = shade(p, &rs, &ray, hit);
+                    result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+                }
+                for (int i = 1; i < maxb; i++) {
+                    hit = trace_logged(p, &ray, cn);
+                    if (!(i == 1 && skyboxS)) cn->rays++;
+                    f3 e = ray.energy;
+                    f3 s = shade(p, &rs, &ray, hit);
+                    result.x += e.x * s.x / fspp; result.y += e.y * s.y / fspp; result.z += e.z * s.z / fspp;
+                    if (!any3(ray.energy)) break;
+                }
+                out4[0] = result.x; out4[1] = result.y; out4[2] = result.z; out4[3] = alphaNew;
+            }
+        } else {                                   /* renderMode >= 11, SH:1071-1104: the frozen frame seen from the moving camera */
+            if (on_screen && !skyboxS) { for (int k = 0; k < 4; k++) out4[k] = bl[k]; }   /* SH:1097 */
+            else { out4[0] = out4[1] = out4[2] = 0.0f; out4[3] = 1.0f; }             /* SH:1102 */
         }
     }
+    return spp > 0;
 }
 
 int pto_render(const PtoPrepared *p, const PtFrameParams *prm, int W, int H,
@@ -762,10 +888,11 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
     if (!p || !prm || !result || W <= 0 || H <= 0 || prm->max_bounces < 1) return 1;
     const int mode = prm->render_mode;
     const int stripes = mode == 5 || mode == 6;
-    if (mode != 0 && mode != 1 && mode != 2 && !stripes) return 1;
+    const int full_reproj = mode == 7 || mode == 8;
+    if (mode < 0 || mode == 9 || mode > 12) return 1;       /* RayTracingMaster.cs:977-990 */
     if (mode != 1 && !result1) return 1;
-    if (mode == 0 && !result2) return 1;
-    if (stripes && (prm->divisions < 1 || prm->divisions > PT_MAX_CAMERA_HISTORY || prm->counter < 0 || prm->counter >= prm->divisions)) return 1;
+    if ((mode == 0 || full_reproj) && !result2) return 1;
+    if ((stripes || full_reproj) && (prm->divisions < 1 || prm->divisions > PT_MAX_CAMERA_HISTORY || prm->counter < 0 || prm->counter >= prm->divisions)) return 1;
     /* the four uniform arrays: elements never uploaded hold zeros */
     PtCameraHistory *cams = (PtCameraHistory *)calloc(PT_MAX_CAMERA_HISTORY, sizeof(PtCameraHistory));
     if (!cams) return 1;
@@ -774,12 +901,13 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
     int x0 = 0, y0 = 0, tw = W, th = H;
     if (prm->tile_w > 0 && prm->tile_h > 0) { x0 = prm->tile_x0; y0 = prm->tile_y0; tw = prm->tile_w; th = prm->tile_h; }
     if (x0 < 0 || y0 < 0 || x0 + tw > W || y0 + th > H) { free(cams); return 1; }
-    if ((mode == 0 || stripes) && (tw != W || th != H)) { free(cams); return 1; }   /* these modes read across pixels: whole frames only */
+    if ((mode == 0 || stripes || full_reproj || mode >= 11) && (tw != W || th != H)) { free(cams); return 1; }   /* whole frames only */
     if (threads <= 0) threads = 1;
     const int screen_passes = mode == 0 && prm->depth != 1 && prm->samples_per_pixel > 0;
-    /* SH:728-736 for every dispatched thread, before any of them goes on:
-     * Result1 = Result (renderMode 2) or Result1 = Result2 (renderMode 0) */
-    if (mode == 0 || mode == 2) {
+    /* SH:728-736 for every dispatched thread, before any of them goes on: Result1 = Result2 (renderMode 0) or
+     * Result1 = Result (renderMode 2, 3, 4, 10; renderMode 1 too in the shader, where Result1 is not read and
+     * the accumulation owns that target) */
+    if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10) {
         const float *src = mode == 0 ? result2 : result;
         for (int y = y0; y < y0 + th; y++)
             memcpy(result1 + 4 * ((size_t)y * W + x0), src + 4 * ((size_t)y * W + x0), (size_t)tw * 4 * sizeof(float));
@@ -790,6 +918,12 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
         denoised = (float *)malloc((size_t)W * H * 4 * sizeof(float));
         if (!seeds || !denoised) { free(seeds); free(denoised); free(cams); return 1; }
     }
+    /* renderMode 7 / 8, first dispatch of a cycle: which threads get as far as SH:944-947 */
+    unsigned char *reached_end = NULL;
+    if (full_reproj && prm->counter % prm->divisions == 0) {
+        reached_end = (unsigned char *)calloc((size_t)W * H, 1);
+        if (!reached_end) { free(seeds); free(denoised); free(cams); return 1; }
+    }
     /* the path tracer; renderMode 0 writes its (reprojected) radiance to Result2, SH:912-924 */
     float *trace_out = (mode == 0 && prm->depth != 1) ? result2 : result;
     uint64_t a = 0, b = 0, c = 0, d = 0;
@@ -798,7 +932,9 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
         Counters cn = {0, 0, 0, 0, NULL, 0, 0};
         for (int x = x0; x < x0 + tw; x++) {
             size_t px = (size_t)y * W + x;
-            cs_main(p, prm, W, H, x, y, trace_out + 4 * px, hit_ids ? hit_ids + px : NULL, &cn, &hs, seeds ? seeds + px : NULL);
+            int reached = cs_main(p, prm, W, H, x, y, trace_out + 4 * px, full_reproj ? result2 + 4 * px : NULL,
+                                  hit_ids ? hit_ids + px : NULL, &cn, &hs, seeds ? seeds + px : NULL);
+            if (reached_end) reached_end[px] = (unsigned char)reached;
         }
         a += cn.trace_calls; b += cn.rays; c += cn.paths; d += cn.prims;
     }
@@ -825,6 +961,15 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
             if (fy > fh - stripe * (float)prm->counter || fy < fh - stripe * (float)(prm->counter + 1)) continue;
             memcpy(result1 + 4 * (size_t)y * W, result + 4 * (size_t)y * W, (size_t)W * 4 * sizeof(float));
         }
+    }
+    if (reached_end) {
+        /* SH:944-947: Result1 = Result2 and Result = Result2, once no thread reads Result1 any more */
+        for (size_t px = 0; px < (size_t)W * H; px++)
+            if (reached_end[px]) {
+                memcpy(result1 + 4 * px, result2 + 4 * px, 4 * sizeof(float));
+                memcpy(result + 4 * px, result2 + 4 * px, 4 * sizeof(float));
+            }
+        free(reached_end);
     }
     free(cams);
     if (stats) { stats->trace_calls = a; stats->rays = b; stats->paths = c; stats->prims_tested = d; }
@@ -1013,7 +1158,7 @@ int pto_path_dump(const PtoPrepared *p, const PtFrameParams *prm, int W, int H, 
 {
     Counters cn = {0, 0, 0, 0, log, cap, 0};
     float out4[4]; int32_t id;
-    cs_main(p, prm, W, H, idx, idy, out4, &id, &cn, NULL, NULL);
+    cs_main(p, prm, W, H, idx, idy, out4, NULL, &id, &cn, NULL, NULL);
     return cn.log_n;
 }
 

@@ -114,9 +114,9 @@ class Oracle:
         return img, ids, {k: getattr(st, k) for k, _ in PtoStats._fields_}
 
     def render_history(self, params, history, width, height, result, result1, threads=1, result2=None):
-        """renderMode 0, 1 or 2 with the camera history `history` (list of PtCameraHistory).  `result` (previous frame on
-        entry, new frame on return), `result1` (the history image) and, for renderMode 0, `result2` (the accumulated
-        radiance) are (H, W, 4) float32 arrays updated in place."""
+        """Any renderMode with the camera history `history` (list of PtCameraHistory).  `result` (previous frame on
+        entry, new frame on return), `result1` (the history image) and, for renderMode 0, 7 and 8, `result2` (the
+        accumulated radiance / the frame being assembled) are (H, W, 4) float32 arrays updated in place."""
         for a in (result, result1) + ((result2,) if result2 is not None else ()):
             assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == (height, width, 4)
         ids = np.full((height, width), -1, np.int32)

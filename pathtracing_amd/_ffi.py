@@ -27,7 +27,7 @@ class PtFrameParams(C.Structure):
                 ("accumulate", C.c_int32), ("tile_x0", C.c_int32), ("tile_y0", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("pixel_offset", C.c_float * 2),
                 ("directional_light", C.c_float * 4), ("accumulation_frames", C.c_int32),
-                ("divisions", C.c_int32), ("counter", C.c_int32)]
+                ("divisions", C.c_int32), ("counter", C.c_int32), ("left_eye", C.c_int32)]
 
 
 class PtCameraHistory(C.Structure):

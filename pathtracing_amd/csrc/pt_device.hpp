@@ -81,6 +81,12 @@ struct RenderArgs {
     // for the denoiser's hash (SH:564)
     float4 *result2;
     float *seed_out;
+    // the remaining renderModes; read by the extended kernel only (path_sched_mat_kernel)
+    int32_t left_eye;             // _leftEye, renderMode 4
+    int32_t cam_old;              // renderMode 7 / 8: c2w / ip hold a history camera and rays are built as CreateCameraRayOld does
+    float alpha_origin[3];        // renderMode 7 / 8: origin of the CURRENT camera, which the alpha channel measures from (SH:940-941)
+    const float *skip_t;          // renderMode 8: t of every pixel's current primary hit; pixels with a miss are not traced (SH:760-763)
+    int32_t copy_all;             // renderMode 7 / 8, first dispatch of a cycle: the pixel also goes to Result1 and Result (SH:944-947)
 };
 
 constexpr int kBlock = 256;            // 4 waves
@@ -514,15 +520,24 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
 }
 
 // SH:108-120 with uv = id.xy / (W,H) * 2 - 1 (SH:842)
+// EXT: honour RenderArgs::cam_old - CreateCameraRayOld (SH:374-387) puts clip-space z = 1 where CreateCameraRay has 0,
+// taken as ((M0*u + M1*v) + M2) + M3.
+template <bool EXT = false>
 __device__ __forceinline__ void camera_ray(const RenderArgs &a, int px, int py, f3 &o, f3 &d)
 {
     float u = (float)px / (float)a.W * 2.0f - 1.0f;
     float v = (float)py / (float)a.H * 2.0f - 1.0f;
     o = pt_make3(a.c2w[12], a.c2w[13], a.c2w[14]);
     f3 dir;
-    dir.x = pt_fma(a.ip[4], v, a.ip[0] * u) + a.ip[12];
-    dir.y = pt_fma(a.ip[5], v, a.ip[1] * u) + a.ip[13];
-    dir.z = pt_fma(a.ip[6], v, a.ip[2] * u) + a.ip[14];
+    if (EXT && a.cam_old) {
+        dir.x = (pt_fma(a.ip[4], v, a.ip[0] * u) + a.ip[8]) + a.ip[12];
+        dir.y = (pt_fma(a.ip[5], v, a.ip[1] * u) + a.ip[9]) + a.ip[13];
+        dir.z = (pt_fma(a.ip[6], v, a.ip[2] * u) + a.ip[10]) + a.ip[14];
+    } else {
+        dir.x = pt_fma(a.ip[4], v, a.ip[0] * u) + a.ip[12];
+        dir.y = pt_fma(a.ip[5], v, a.ip[1] * u) + a.ip[13];
+        dir.z = pt_fma(a.ip[6], v, a.ip[2] * u) + a.ip[14];
+    }
     dir = pt_mul_dir(a.c2w, dir);
     d = pt_normalize3(dir);
 }
@@ -625,6 +640,73 @@ __device__ __forceinline__ float4 reproject_pixel(const RenderArgs &a, f3 result
                                bl.z * (divisor - 1.0f) / divisor + result.z / divisor, dist_old);
     }
     return make_float4(result.x, result.y, result.z, alpha_dist);
+}
+
+// FindCameraRayVR(input), SH:418-437: FindCameraRay with the headset's aspect ratio and per-eye offsets hard-coded.
+__device__ __forceinline__ f2 find_camera_ray_vr(const RenderArgs &a, f3 dir)
+{
+    const float m11 = a.old_proj[5], m22 = a.old_proj[10], m23 = a.old_proj[14];
+    const float near = -m23 / m22;
+    const float far = -(near * m22) / (1.0f - m22);
+    const f3 pos = pt_scale3(pt_normalize3(dir), near + (far - near));
+    const float ratio = 2240.0f / 2016.0f;
+    const f3 toCam = pt_mul_dir(a.old_w2c, pos);
+    const float height = toCam.z / m11;
+    const float width = ratio * height;
+    const float uvx = (toCam.x - width * (2240.0f / 2016.0f)) / width;
+    const float uvy = (toCam.y - height) / height;
+    const float ph = (float)(uint32_t)a.H;
+    f2 r;
+    r.x = (1.0f - uvx * (ph * ratio / 2.043f)) - (a.left_eye ? 156.0f : 538.0f);
+    r.y = (1.0f - uvy * (ph / 2.0f)) - (a.left_eye ? -1.3f : -0.6f);
+    return r;
+}
+
+// What renderMode 3 (SH:986-1019), 4 (SH:1021-1046) and 10 (SH:1048-1069) look up for a pixel's primary hit.
+struct HistoryLookup { bool on_screen; float4 bilinear; float4 texel; float dist_old; f2 uv; };
+__device__ __forceinline__ HistoryLookup history_lookup(const RenderArgs &a, f3 hit_pos)
+{
+    HistoryLookup h;
+    const f3 origin_old = pt_make3(a.old_c2w[12], a.old_c2w[13], a.old_c2w[14]);
+    const f3 to_hit = pt_sub3(hit_pos, origin_old);
+    h.dist_old = pt_length3(to_hit);
+    h.uv = a.render_mode == 4 ? find_camera_ray_vr(a, to_hit) : find_camera_ray(a, to_hit);
+    h.on_screen = h.uv.x < (float)a.W && h.uv.x > 0.0f && h.uv.y < (float)a.H && h.uv.y > 0.0f;
+    h.bilinear = h.texel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (h.on_screen) { h.bilinear = bilinear_history(a, h.uv); h.texel = history_load(a, h.uv.x, h.uv.y); }
+    return h;
+}
+
+// renderMode 10: does the pixel show its history instead of a traced path (SH:1053-1055)?
+__device__ __forceinline__ bool history_covers(const HistoryLookup &h, bool sky)
+{
+    return h.on_screen && (pt_abs(h.dist_old - h.bilinear.w) < h.dist_old * 0.05f || h.bilinear.w > 80.0f) && !sky;
+}
+
+// The value renderMode 3 or 4 writes to Result for a finished pixel.
+__device__ __forceinline__ float4 reproject_pixel_ext(const RenderArgs &a, f3 result, f3 hit_pos, bool sky, float alpha_dist)
+{
+    const HistoryLookup h = history_lookup(a, hit_pos);
+    if (a.render_mode == 3) {
+        const bool take = h.on_screen && (pt_abs(h.dist_old - h.texel.w) < h.dist_old * 0.05f || h.texel.w > 80.0f) && !sky;   // SH:995-997
+        if (!take) return make_float4(result.x, result.y, result.z, alpha_dist);                                          // SH:1011
+        const float divisor = 10.0f;
+        const float4 n0 = history_load(a, h.uv.x + 1.0f, h.uv.y + 1.0f), n1 = history_load(a, h.uv.x - 1.0f, h.uv.y - 1.0f);   // SH:1000-1001
+        const float4 n2 = history_load(a, h.uv.x + 1.0f, h.uv.y + -1.0f), n3 = history_load(a, h.uv.x - 1.0f, h.uv.y - -1.0f); // SH:1002-1003
+        float4 out;
+        out.x = result.x / 2.5f; out.x += h.bilinear.x / 5.0f; out.x += n0.x / divisor; out.x += n1.x / divisor; out.x += n2.x / divisor; out.x += n3.x / divisor;
+        out.y = result.y / 2.5f; out.y += h.bilinear.y / 5.0f; out.y += n0.y / divisor; out.y += n1.y / divisor; out.y += n2.y / divisor; out.y += n3.y / divisor;
+        out.z = result.z / 2.5f; out.z += h.bilinear.z / 5.0f; out.z += n0.z / divisor; out.z += n1.z / divisor; out.z += n2.z / divisor; out.z += n3.z / divisor;
+        out.w = alpha_dist;                                                                                               // SH:1005
+        return out;
+    }
+    // renderMode 4: the distance test reads the unfiltered texel, the far-away test the filtered one (SH:1033-1035)
+    const bool take = h.on_screen && (pt_abs(h.dist_old - h.texel.w) < h.dist_old * 0.05f || h.bilinear.w > 80.0f) && !sky;
+    if (!take) return make_float4(result.x, result.y, result.z, alpha_dist);                                              // SH:1043
+    const float divisor = a.accumulation_frames;
+    return make_float4(h.bilinear.x * (divisor - 1.0f) / divisor + result.x / divisor,                                    // SH:1037
+                       h.bilinear.y * (divisor - 1.0f) / divisor + result.y / divisor,
+                       h.bilinear.z * (divisor - 1.0f) / divisor + result.z / divisor, h.dist_old);
 }
 
 // Converged-image update fused into the final write: AddMat.shader:44-63 with
@@ -782,6 +864,22 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     float t_primary = s1.w;
                     Rng rs = {s0.w, pixel_dot(pix_x, pix_y)};
                     f3 hit_pos;
+                    bool from_history = false;
+                    if (MAT && a.render_mode == 10 && bounce == 0 && sample == 0) {
+                        // SH:1048-1057: a primary hit the history already shows is copied from there and no path is traced.
+                        // The test depends on the camera ray and Result1 only, so it is the same for every sample of the
+                        // pixel and is made once.
+                        const bool sky = !(tbest < PT_INF);
+                        const HistoryLookup h = history_lookup(a, sky ? pt_make3(0, 0, 0) : pt_along3(o, tbest, d));
+                        if (history_covers(h, sky)) {
+                            const size_t p = (size_t)pix_y * a.W + pix_x;
+                            a.result[p] = h.bilinear;
+                            if (a.hit_ids) a.hit_ids[p] = idbest;
+                            from_history = true;
+                            finished = true;
+                        }
+                    }
+                    if (!from_history) {
                     shade<MAT>(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
                     bool path_done;
                     if (bounce == 0) {
@@ -799,7 +897,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         if (sample < a.spp) {                          // next sample of the same pixel, SH:839
                             bounce = 0;
                             energy = pt_make3(1, 1, 1);
-                            camera_ray(a, pix_x, pix_y, o, d);
+                            camera_ray<MAT>(a, pix_x, pix_y, o, d);
                             cnt.w++;
                             if (a.reuse_primary) {
                                 // SH:842 has no jitter: every sample of a pixel starts with the same camera ray, so
@@ -811,13 +909,20 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                             // its distance from the camera; every sample of a pixel has the same primary ray
                             size_t p = (size_t)pix_y * a.W + pix_x;
                             f3 co, cd;
-                            camera_ray(a, pix_x, pix_y, co, cd);
+                            camera_ray<MAT>(a, pix_x, pix_y, co, cd);
                             const bool sky = !(t_primary < PT_INF);
                             const f3 hit_pos0 = sky ? pt_make3(0, 0, 0) : pt_along3(co, t_primary, cd);
-                            const float alpha_dist = pt_length3(pt_sub3(hit_pos0, co));
+                            const bool full_reproj = MAT && (a.render_mode == 7 || a.render_mode == 8);
+                            const f3 alpha_from = full_reproj ? pt_make3(a.alpha_origin[0], a.alpha_origin[1], a.alpha_origin[2]) : co;
+                            const float alpha_dist = pt_length3(pt_sub3(hit_pos0, alpha_from));
                             float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
-                            if (a.render_mode != 1) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist, pix_y);
+                            if (MAT && (a.render_mode == 3 || a.render_mode == 4)) fresh = reproject_pixel_ext(a, result, hit_pos0, sky, alpha_dist);
+                            else if (a.render_mode == 0 || a.render_mode == 2) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist, pix_y);
                             if (a.render_mode == 0) { a.result2[p] = fresh; a.seed_out[p] = rs.seed; }
+                            else if (full_reproj) {                    // SH:938-948
+                                a.result2[p] = fresh;
+                                if (a.copy_all) { a.converged[p] = fresh; a.result[p] = fresh; }
+                            }
                             else a.result[p] = fresh;
                             if (a.hit_ids) a.hit_ids[p] = primary_id;
                             accumulate_pixel(a, p, fresh);
@@ -830,6 +935,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         *ls1 = make_float4(result.x, result.y, result.z, t_primary);
                         *ls2 = make_int4(px.x, sample | (bounce << 20), (int)primary_rec, primary_id);
                     }
+                    }   // !from_history
                 }
             }
             // ---- new pixels for lanes without one.  The wave claims them from its current shard of the frame with one
@@ -859,11 +965,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         no_more = true;
                     } else {
                         int x, y;
-                        if (item_pixel(a, item, x, y)) {
+                        if (item_pixel(a, item, x, y) && !(MAT && a.skip_t && !(a.skip_t[(size_t)y * a.W + x] < PT_INF))) {
                             *ls0 = make_float4(1.0f, 1.0f, 1.0f, a.seed);
                             *ls1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                             *ls2 = make_int4(x | (y << 16), 0, 0, -1);   // sample 0, bounce 0, no primary hit yet
-                            camera_ray(a, x, y, o, d);
+                            camera_ray<MAT>(a, x, y, o, d);
                             cnt.w++;
                             new_ray = true;
                         }

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void taa_kernel(cons
 // One pixel per thread and pass over the rectangle (8x8 pixel blocks, so a wave's rays are neighbours and walk
 // the tree almost in step); no path state, no regeneration, so none of the persistent kernel's machinery.
 // what == 1: Result = distance / 16 in all channels (+ hit ids); what == 2: t of the hit to a.seed_out,
-// rows skip_lo .. skip_hi (the stripe being path-traced) left out.
+// rows skip_lo .. skip_hi (the stripe being path-traced) left out; what == 3: as 1, but only for pixels whose
+// entry in a.skip_t is finite.
 template <int WIDE>
 __global__ __launch_bounds__(kBlock) void primary_kernel(const RenderArgs a, int what, int skip_lo, int skip_hi)
 {
@@ -160,14 +161,15 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const RenderArgs a, int
     for (uint32_t item = tid; item < a.total_items; item += n_threads) {
         int x = 0, y = 0;
         if (!item_pixel(a, item, x, y) || (what == 2 && y >= skip_lo && y <= skip_hi)) continue;
+        const size_t p = (size_t)y * a.W + x;
+        if (what == 3 && !(a.skip_t[p] < PT_INF)) continue;               // renderMode 8: the thread returned at SH:760-763
         f3 o, d;
         camera_ray(a, x, y, o, d);
         float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
         intersect_ground_plane(o, d, t, id);
         traverse<WIDE>(a.sc, o, d, t, id, rec, st, cn, cp);
         rays++;
-        const size_t p = (size_t)y * a.W + x;
-        if (what == 1) {
+        if (what == 1 || what == 3) {
             const float dis = t / 16.0f;                                  // SH:806-807
             a.result[p] = make_float4(dis, dis, dis, dis);
             if (a.hit_ids) a.hit_ids[p] = id;
@@ -246,11 +248,12 @@ __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void display_denoise
                                          pt_min(pt_max(lerp1(a.z, b.z, p_w), 0.0f), 1.0f), 0.0f);   // :183
 }
 
-// ---- renderMode 5 / 6: pixels outside the stripe being rendered (SH:742-789) ----
+// ---- pixels that show the history instead of a traced path: renderMode 5 / 6 outside the stripe being rendered
+// (SH:742-789), every pixel of renderMode 7 / 8 (same lines) and of renderMode 11 / 12 (SH:1071-1104) ----
 
 struct StripeArgs {
     const PtCameraHistory *cams;   // the four *Old arrays, PT_MAX_CAMERA_HISTORY elements
-    const float *t_primary;        // renderMode 6: t of every pixel's primary hit (+inf = miss)
+    const float *t_primary;        // even modes: t of every pixel's primary hit (+inf = miss)
     int32_t divisions, counter, mode;
 };
 
@@ -274,35 +277,39 @@ __device__ __forceinline__ f2 find_camera_ray_in(const PtCameraHistory &cam, int
     return r;
 }
 
-// One thread per pixel; pixels of the stripe being path-traced are left alone.
+// One thread per pixel; in renderMode 5 / 6 pixels of the stripe being path-traced are left alone.
 __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void stripe_reproject_kernel(const RenderArgs a, const StripeArgs sa)
 {
     const int x = blockIdx.x * kScreenBlockX + threadIdx.x, y = blockIdx.y * kScreenBlockY + threadIdx.y;
     if (x >= a.W || y >= a.H) return;
     const float fh = (float)a.H, fy = (float)y;
+    const bool partial = sa.mode == 5 || sa.mode == 6;
     const float stripe = fh / (float)sa.divisions;                                            // SH:742
-    if (!(fy > fh - stripe * (float)sa.counter || fy < fh - stripe * (float)(sa.counter + 1))) return;   // SH:751
+    if (partial && !(fy > fh - stripe * (float)sa.counter || fy < fh - stripe * (float)(sa.counter + 1))) return;   // SH:751
     const size_t p = (size_t)y * a.W + x;
     f3 o, d;
-    camera_ray(a, x, y, o, d);                                                                // SH:753-754
-    f3 hit_pos = pt_along3(o, 10.0f, d);                                                      // SH:755
-    if (sa.mode % 2 == 0) {                                                                   // SH:757-764
+    camera_ray(a, x, y, o, d);                                                                // SH:753-754, SH:848
+    f3 hit_pos = pt_along3(o, 10.0f, d);                                                      // SH:755, SH:855
+    if (sa.mode % 2 == 0) {                                                                   // SH:757-764, SH:858-863
         const float t = sa.t_primary[p];
         if (!(t < PT_INF)) {
-            const f3 sky = sky_sample(a.sc, d);
-            a.result[p] = make_float4(sky.x, sky.y, sky.z, 1.0f);
+            if (sa.mode == 12) a.result[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);             // SH:1078, SH:1102
+            else { const f3 sky = sky_sample(a.sc, d); a.result[p] = make_float4(sky.x, sky.y, sky.z, 1.0f); }   // SH:760-762
             return;
         }
         hit_pos = pt_along3(o, t, d);
     }
-    const int one_mod = 1 % sa.divisions;
-    int frames_back = (int)(((float)sa.divisions - fy / stripe) - (float)one_mod);            // SH:766
-    frames_back = frames_back < 0 ? 0 : frames_back > PT_MAX_CAMERA_HISTORY - 1 ? PT_MAX_CAMERA_HISTORY - 1 : frames_back;   // stay inside the arrays
+    int frames_back = 0;
+    if (partial) {
+        const int one_mod = 1 % sa.divisions;
+        frames_back = (int)(((float)sa.divisions - fy / stripe) - (float)one_mod);            // SH:766
+        frames_back = frames_back < 0 ? 0 : frames_back > PT_MAX_CAMERA_HISTORY - 1 ? PT_MAX_CAMERA_HISTORY - 1 : frames_back;   // stay inside the arrays
+    }
     const PtCameraHistory &cam = sa.cams[frames_back];
     const f3 origin_old = pt_make3(cam.camera_to_world[12], cam.camera_to_world[13], cam.camera_to_world[14]);
-    const f2 uv = find_camera_ray_in(cam, a.W, a.H, pt_sub3(hit_pos, origin_old));            // SH:770
-    float4 out = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                         // SH:780
-    if (uv.x < (float)a.W && uv.x > 0.0f && uv.y < (float)a.H && uv.y > 0.0f) out = bilinear_history(a, uv);   // SH:772-776
+    const f2 uv = find_camera_ray_in(cam, a.W, a.H, pt_sub3(hit_pos, origin_old));            // SH:770, SH:1074
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                         // SH:780, SH:1102
+    if (uv.x < (float)a.W && uv.x > 0.0f && uv.y < (float)a.H && uv.y > 0.0f) out = bilinear_history(a, uv);   // SH:772-776, SH:1076-1097
     a.result[p] = out;
 }
 

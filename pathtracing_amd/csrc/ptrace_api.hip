@@ -694,7 +694,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     a.tiles_x = (tw + 7) / 8;
     const int tiles_y = (th + 7) / 8;
     a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
-    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !ctx->d_mesh_mat && !a.reuse_primary) return render_wavefront(ctx, a);
+    const bool extended = ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
+    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
     {
         // Few samples per pixel: pixels are claimed often, and one counter would serialise the claims at the L2.  Many
@@ -713,7 +714,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
     a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
-    if (ctx->d_mesh_mat) {
+    if (extended) {
         if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_mat_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
@@ -762,8 +763,10 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_render before pt_resize");
     const int mode = p->render_mode;
     const bool stripes = mode == 5 || mode == 6;
-    if (mode != 0 && mode != 1 && mode != 2 && !stripes)
-        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: only renderMode 0 (Denoise), 1 (Default), 2 (Reproj), 5 and 6 (PartialFrameReproj[Depth]) are implemented");
+    const bool full_reproj = mode == 7 || mode == 8;
+    const bool pause = mode == 11 || mode == 12;
+    if (mode < 0 || mode == 9 || mode > 12)
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode must be one of RayTracingMaster.RenderMode's values: 0..8, 10, 11, 12");
     if (mode != 1 && p->accumulate != PT_ACCUM_NONE)
         return fail(ctx, PT_ERR_INVALID, "pt_render: every renderMode but 1 uses the converged target as its history; accumulate must be PT_ACCUM_NONE");
     if (p->max_bounces < 1 || p->max_bounces > 4095) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be 1..4095");
@@ -773,10 +776,10 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     if (p->tile_w > 0 && p->tile_h > 0) { x0 = p->tile_x0; y0 = p->tile_y0; tw = p->tile_w; th = p->tile_h; }
     if (x0 < 0 || y0 < 0 || (int64_t)x0 + tw > ctx->W || (int64_t)y0 + th > ctx->H)
         return fail(ctx, PT_ERR_INVALID, "pt_render: tile outside the image");
-    if ((mode == 0 || stripes) && (tw != ctx->W || th != ctx->H))
-        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode 0, 5 and 6 read across pixels and render whole frames only");
-    if (stripes && (p->divisions < 1 || p->divisions > PT_MAX_CAMERA_HISTORY || p->counter < 0 || p->counter >= p->divisions))
-        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 5/6 need 1 <= divisions <= 100 and 0 <= counter < divisions");
+    if ((mode == 0 || stripes || full_reproj || pause) && (tw != ctx->W || th != ctx->H))
+        return fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: renderMode 0, 5..8, 11 and 12 render whole frames only");
+    if ((stripes || full_reproj) && (p->divisions < 1 || p->divisions > PT_MAX_CAMERA_HISTORY || p->counter < 0 || p->counter >= p->divisions))
+        return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 5..8 need 1 <= divisions <= 100 and 0 <= counter < divisions");
     DeviceGuard g(ctx->device);
     int rc;
     if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
@@ -785,17 +788,17 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         if ((rc = rebuild_scene(ctx))) return rc;
     }
     const size_t pitch = (size_t)ctx->W * sizeof(float4);
-    if (mode == 0 || mode == 2) {
-        // SH:728-736, Result1 = Result (renderMode 2) or Result2 (renderMode 0) over the dispatched rectangle,
-        // finished before any pixel is traced
+    if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10) {
+        // SH:728-736, Result1 = Result (renderMode 2, 3, 4, 10) or Result2 (renderMode 0) over the dispatched
+        // rectangle, finished before any pixel is traced
         const float4 *src = mode == 0 ? ctx->result2 : ctx->result;
         PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)y0 * ctx->W + x0, pitch, src + (size_t)y0 * ctx->W + x0, pitch,
                                      (size_t)tw * sizeof(float4), (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
     }
     const bool no_samples = p->depth != 1 && p->samples_per_pixel <= 0;   // the shader's sample loop does not run
-    if (no_samples && !stripes) return PT_OK;
+    if (no_samples && !stripes && !full_reproj) return PT_OK;
     const bool screen_passes = mode == 0 && p->depth != 1;
-    if ((screen_passes || mode == 6) && (rc = ensure_screen_scratch(ctx))) return rc;
+    if ((screen_passes || mode == 6 || mode == 8 || mode == 12) && (rc = ensure_screen_scratch(ctx))) return rc;
 
     RenderArgs a;
     a.sc = scene_dev(ctx);
@@ -809,6 +812,8 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
     a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
     a.reuse_primary = ctx->reuse_primary;
     a.render_mode = stripes ? 1 : mode;   // the stripe being rendered is written as renderMode 1 writes (SH:933-936)
+    a.left_eye = p->left_eye; a.cam_old = 0; a.skip_t = nullptr; a.copy_all = 0;
+    a.alpha_origin[0] = p->camera_to_world[12]; a.alpha_origin[1] = p->camera_to_world[13]; a.alpha_origin[2] = p->camera_to_world[14];
     a.history = ctx->conv;
     a.accumulation_frames = (float)p->accumulation_frames;
     std::memcpy(a.old_c2w, ctx->camera_history[0].camera_to_world, sizeof a.old_c2w);
@@ -821,15 +826,17 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         PT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->epoch_open = true;
     }
-    if (stripes) {
+    if (stripes || full_reproj || pause) {
         // rows of the stripe being rendered: the shader's own float comparisons (SH:742,751), row by row
-        const float fh = (float)ctx->H, stripe = fh / (float)p->divisions;
         int s_lo = ctx->H, s_hi = -1;
-        for (int y = 0; y < ctx->H; y++) {
-            const float fy = (float)y;
-            if (!(fy > fh - stripe * (float)p->counter || fy < fh - stripe * (float)(p->counter + 1))) { s_lo = std::min(s_lo, y); s_hi = std::max(s_hi, y); }
+        if (!pause) {
+            const float fh = (float)ctx->H, stripe = fh / (float)p->divisions;
+            for (int y = 0; y < ctx->H; y++) {
+                const float fy = (float)y;
+                if (!(fy > fh - stripe * (float)p->counter || fy < fh - stripe * (float)(p->counter + 1))) { s_lo = std::min(s_lo, y); s_hi = std::max(s_hi, y); }
+            }
         }
-        const int s_rows = s_hi >= s_lo ? s_hi - s_lo + 1 : 0;
+        int s_rows = s_hi >= s_lo ? s_hi - s_lo + 1 : 0;
         constexpr size_t cam_bytes = sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY;
         if (ctx->cams_dirty || !ctx->d_cams[ctx->cam_slot]) {
             const int i = ctx->cam_slot = (ctx->cam_slot + 1) % pt_context::kCamRing;
@@ -843,23 +850,48 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
             PT_HIP(ctx, hipMemcpyAsync(ctx->d_cams[i], ctx->h_cams[i], cam_bytes, hipMemcpyHostToDevice, ctx->stream));
             ctx->cams_dirty = false;
         }
-        if (mode == 6) {
-            // SH:757-759: the other pixels' current primary hits, traced by the path kernel with nothing after the first hit
+        const bool have_samples = !no_samples;      // the pause modes write inside the sample loop (SH:1071-1104)
+        if (mode % 2 == 0 && (!pause || (have_samples && a.depth != 1))) {
+            // SH:757-759, SH:858-863: the pixels' current primary hits (renderMode 6: of the pixels outside the stripe)
             RenderArgs prim = a;
-            if ((rc = launch_primary(ctx, prim, 2, 0, 0, ctx->W, ctx->H, s_rows ? s_lo : 1, s_rows ? s_hi : 0))) return rc;
+            const bool whole = mode != 6 || !s_rows;
+            if ((rc = launch_primary(ctx, prim, 2, 0, 0, ctx->W, ctx->H, whole ? 1 : s_lo, whole ? 0 : s_hi))) return rc;
         }
         StripeArgs sa;
-        sa.cams = ctx->d_cams[ctx->cam_slot]; sa.t_primary = ctx->d_seeds; sa.divisions = p->divisions; sa.counter = p->counter; sa.mode = mode;
+        sa.cams = ctx->d_cams[ctx->cam_slot]; sa.t_primary = ctx->d_seeds; sa.divisions = pause ? 1 : p->divisions; sa.counter = p->counter; sa.mode = mode;
         const dim3 blk(kScreenBlockX, kScreenBlockY), grd((ctx->W + kScreenBlockX - 1) / kScreenBlockX, (ctx->H + kScreenBlockY - 1) / kScreenBlockY);
-        hipLaunchKernelGGL(stripe_reproject_kernel, grd, blk, 0, ctx->stream, a, sa);
-        PT_HIP(ctx, hipGetLastError());
-        PT_HIP(ctx, hipEventRecord(ctx->ev_cams[ctx->cam_slot], ctx->stream));
-        ctx->cams_used[ctx->cam_slot] = true;
-        if (s_rows && a.depth == 1) { if ((rc = launch_primary(ctx, a, 1, 0, s_lo, ctx->W, s_rows, 1, 0))) return rc; }
-        else if (s_rows && !no_samples && (rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
-        if (s_rows && p->depth != 1)   // SH:1108-1112, after every read of Result1 above
-            PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)s_lo * ctx->W, pitch, ctx->result + (size_t)s_lo * ctx->W, pitch,
-                                         (size_t)ctx->W * sizeof(float4), (size_t)s_rows, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!pause || (have_samples && a.depth != 1)) {
+            hipLaunchKernelGGL(stripe_reproject_kernel, grd, blk, 0, ctx->stream, a, sa);
+            PT_HIP(ctx, hipGetLastError());
+            PT_HIP(ctx, hipEventRecord(ctx->ev_cams[ctx->cam_slot], ctx->stream));
+            ctx->cams_used[ctx->cam_slot] = true;
+        }
+        if (pause) {
+            if (a.depth == 1 && (rc = launch_primary(ctx, a, 1, 0, 0, ctx->W, ctx->H, 1, 0))) return rc;   // SH:799-809 comes first
+        } else if (stripes) {
+            if (s_rows && a.depth == 1) { if ((rc = launch_primary(ctx, a, 1, 0, s_lo, ctx->W, s_rows, 1, 0))) return rc; }
+            else if (s_rows && !no_samples && (rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
+            if (s_rows && p->depth != 1)   // SH:1108-1112, after every read of Result1 above
+                PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)s_lo * ctx->W, pitch, ctx->result + (size_t)s_lo * ctx->W, pitch,
+                                             (size_t)ctx->W * sizeof(float4), (size_t)s_rows, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            // renderMode 7 / 8 (SH:786-788, 850-853, 938-948): the first dispatch of a cycle goes on for every pixel, the others for the stripe
+            const bool first = p->counter % p->divisions == 0;
+            if (first) { s_lo = 0; s_rows = ctx->H; }
+            if (mode == 8) a.skip_t = ctx->d_seeds;                      // SH:760-763: a primary miss has returned
+            if (s_rows && a.depth == 1) {
+                if ((rc = launch_primary(ctx, a, mode == 8 ? 3 : 1, 0, s_lo, ctx->W, s_rows, 1, 0))) return rc;
+            } else if (s_rows && !no_samples) {
+                const int fb = (p->counter - 1) % p->divisions;          // -1 on the first dispatch: the current camera (SH:8-11)
+                if (fb >= 0) {
+                    std::memcpy(a.c2w, ctx->camera_history[fb].camera_to_world, sizeof a.c2w);
+                    std::memcpy(a.ip, ctx->camera_history[fb].camera_inverse_projection, sizeof a.ip);
+                }
+                a.cam_old = 1;
+                a.copy_all = first ? 1 : 0;
+                if ((rc = launch_path(ctx, a, 0, s_lo, ctx->W, s_rows))) return rc;
+            }
+        }
     } else if (a.depth == 1) {
         if ((rc = launch_primary(ctx, a, 1, x0, y0, tw, th, 1, 0))) return rc;
     } else {
@@ -883,8 +915,9 @@ int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int c
 {
     if (!ctx) return PT_ERR_INVALID;
     if (count < 0 || count > PT_MAX_CAMERA_HISTORY) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: count must be 0..100");
-    if (count > 0 && !entries) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: entries is NULL");
-    if (count == 0) std::memset(ctx->camera_history.data(), 0, sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY);
+    if (count == 0) return PT_OK;   // an empty list writes nothing into the uniform arrays
+    if (!entries && count != PT_MAX_CAMERA_HISTORY) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: entries is NULL");
+    if (!entries) std::memset(ctx->camera_history.data(), 0, sizeof(PtCameraHistory) * PT_MAX_CAMERA_HISTORY);
     else std::memcpy(ctx->camera_history.data(), entries, sizeof(PtCameraHistory) * (size_t)count);
     ctx->cams_dirty = true;
     return PT_OK;

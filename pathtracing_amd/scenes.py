@@ -104,7 +104,7 @@ def camera_history_entry(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1,
 
 
 def make_params(scene, width, height, *, seed=0.5, spp=1, max_bounces=8, depth=0, accumulate=0, sample_index=0,
-                tile=None, eye=None, target=None, fov=None, render_mode=1, accumulation_frames=0, divisions=0, counter=0):
+                tile=None, eye=None, target=None, fov=None, render_mode=1, accumulation_frames=0, divisions=0, counter=0, left_eye=0):
     """PtFrameParams for `scene`'s default (or the given) camera."""
     c2w, ip = camera_matrices(scene.eye if eye is None else eye, scene.target if target is None else target,
                               scene.fov if fov is None else fov, width / height)
@@ -113,7 +113,7 @@ def make_params(scene, width, height, *, seed=0.5, spp=1, max_bounces=8, depth=0
     p.camera_inverse_projection[:] = ip.tolist()
     p.seed = seed; p.samples_per_pixel = spp; p.max_bounces = max_bounces; p.depth = depth
     p.render_mode = render_mode; p.sample_index = sample_index; p.accumulate = accumulate
-    p.accumulation_frames = accumulation_frames; p.divisions = divisions; p.counter = counter
+    p.accumulation_frames = accumulation_frames; p.divisions = divisions; p.counter = counter; p.left_eye = left_eye
     if tile is not None:
         p.tile_x0, p.tile_y0, p.tile_w, p.tile_h = tile
     p.directional_light[1] = -1.0; p.directional_light[3] = 1.0

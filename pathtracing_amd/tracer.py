@@ -91,6 +91,10 @@ class PathTracer:
         arr = (PtCameraHistory * max(1, len(entries)))(*entries)
         self._check(self._lib.pt_set_camera_history(self._ctx, C.byref(arr), len(entries)), "pt_set_camera_history")
 
+    def clear_camera_history(self):
+        """Every element of the four history arrays back to zero, the state of a new context."""
+        self._check(self._lib.pt_set_camera_history(self._ctx, None, 100), "pt_set_camera_history")
+
     # ---- targets / render ---------------------------------------------------
     def resize(self, width, height):
         self._check(self._lib.pt_resize(self._ctx, int(width), int(height)), "pt_resize")

@@ -11,10 +11,10 @@ def camera_at(scene, k, step=(0.12, 0.05, 0.2)):
     return eye, tuple(float(v) for v in scene.target)
 
 
-def frame_params(scene, W, H, k, spp, max_bounces, frames_n, step=(0.12, 0.05, 0.2), tile=None, depth=0, mode=2):
+def frame_params(scene, W, H, k, spp, max_bounces, frames_n, step=(0.12, 0.05, 0.2), tile=None, depth=0, mode=2, left_eye=0):
     eye, target = camera_at(scene, k, step)
     p = pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=spp, max_bounces=max_bounces, eye=eye, target=target,
-                       render_mode=mode, accumulation_frames=frames_n, tile=tile, depth=depth)
+                       render_mode=mode, accumulation_frames=frames_n, tile=tile, depth=depth, left_eye=left_eye)
     h = pa.camera_history_entry(eye, target, scene.fov, W / H)
     return p, h
 
@@ -37,6 +37,7 @@ def gpu_sequence(tracer, scene, W, H, n_frames, spp=1, max_bounces=4, frames_n=5
     for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED, pa.PT_TARGET_DENOISED):
         tracer.write_target(which, np.zeros((H, W, 4), np.float32))
     mode0 = kw.get("mode", 2) == 0
+    tracer.clear_camera_history()
     hist = []
     out = []
     for k in range(n_frames):
@@ -69,24 +70,65 @@ def stripe_frames(scene, W, H, n_frames, divisions, mode, spp=1, max_bounces=4, 
 
 
 def oracle_stripe_sequence(oracle, scene, W, H, n_frames, divisions, mode, threads=4, **kw):
+    """renderMode 5 .. 8.  Per frame: (Result, Result1, None, stats[, Result2 in renderMode 7 / 8])."""
     result = np.zeros((H, W, 4), np.float32); result1 = np.zeros((H, W, 4), np.float32)
+    result2 = np.zeros((H, W, 4), np.float32) if mode in (7, 8) else None
     state = [pa.PtCameraHistory() for _ in range(100)]          # the shader's uniform arrays: a shorter upload keeps the tail
     out = []
     for p, hist in stripe_frames(scene, W, H, n_frames, divisions, mode, **kw):
+        state[:len(hist)] = hist
+        ids, st = oracle.render_history(p, state, W, H, result, result1, threads=threads, result2=result2)
+        out.append((result.copy(), result1.copy(), ids, st) + ((result2.copy(),) if result2 is not None else ()))
+    return out
+
+
+def gpu_stripe_sequence(tracer, scene, W, H, n_frames, divisions, mode, **kw):
+    for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED, pa.PT_TARGET_DENOISED):
+        tracer.write_target(which, np.zeros((H, W, 4), np.float32))
+    tracer.clear_camera_history()                               # back to all-zero arrays
+    out = []
+    for p, hist in stripe_frames(scene, W, H, n_frames, divisions, mode, **kw):
+        tracer.set_camera_history(hist)                         # an empty list writes nothing, as in the shader's arrays
+        tracer.stats()
+        tracer.render(p)
+        out.append((tracer.read_result(), tracer.read_converged(), None, tracer.stats())
+                   + ((tracer.read_target(pa.PT_TARGET_DENOISED),) if mode in (7, 8) else ()))
+    return out
+
+
+# ---- renderMode 11 / 12: the frame and camera of the moment the host switched to the pause mode stay in Result1 and in
+# the history arrays (RayTracingMaster.cs:513-526 uploads an empty list from then on) while the camera moves on
+
+def pause_frames(scene, W, H, n_warm, n_paused, mode, spp=1, max_bounces=4, step=(0.12, 0.05, 0.2), depth=0):
+    """Per frame: (PtFrameParams, history list uploaded before the dispatch); n_warm frames of renderMode 2 first."""
+    out = []
+    hist = []
+    for k in range(n_warm + n_paused):
+        m = 2 if k < n_warm else mode
+        p, h = frame_params(scene, W, H, k, 1 if m >= 10 else spp, max_bounces, 5, step=step, mode=m, depth=depth if m >= 10 else 0)
+        out.append((p, list(hist)))
+        hist = [h] if m < 11 else []                            # :513-526: cleared every frame, refilled only below mode 11
+    return out
+
+
+def oracle_pause_sequence(oracle, scene, W, H, n_warm, n_paused, mode, threads=4, **kw):
+    result = np.zeros((H, W, 4), np.float32); result1 = np.zeros((H, W, 4), np.float32)
+    state = [pa.PtCameraHistory() for _ in range(100)]
+    out = []
+    for p, hist in pause_frames(scene, W, H, n_warm, n_paused, mode, **kw):
         state[:len(hist)] = hist
         ids, st = oracle.render_history(p, state, W, H, result, result1, threads=threads)
         out.append((result.copy(), result1.copy(), ids, st))
     return out
 
 
-def gpu_stripe_sequence(tracer, scene, W, H, n_frames, divisions, mode, **kw):
+def gpu_pause_sequence(tracer, scene, W, H, n_warm, n_paused, mode, **kw):
     for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED):
         tracer.write_target(which, np.zeros((H, W, 4), np.float32))
-    tracer.set_camera_history([])                               # back to all-zero arrays
+    tracer.clear_camera_history()
     out = []
-    for p, hist in stripe_frames(scene, W, H, n_frames, divisions, mode, **kw):
-        if hist:
-            tracer.set_camera_history(hist)
+    for p, hist in pause_frames(scene, W, H, n_warm, n_paused, mode, **kw):
+        tracer.set_camera_history(hist)
         tracer.stats()
         tracer.render(p)
         out.append((tracer.read_result(), tracer.read_converged(), None, tracer.stats()))

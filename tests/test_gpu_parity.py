@@ -300,7 +300,7 @@ def test_error_paths(tracer):
     for bad in (dict(max_bounces=0), dict(tile=(8, 8, 16, 16)), dict(accumulate=9)):
         with pytest.raises(pa.PtraceError):
             tracer.render(pa.make_params(s, 16, 16, **bad))
-    p = pa.make_params(s, 16, 16); p.render_mode = 7
+    p = pa.make_params(s, 16, 16); p.render_mode = 9
     with pytest.raises(pa.PtraceError, match="renderMode"):
         tracer.render(p)
     with pytest.raises(pa.PtraceError, match="outside"):
@@ -459,7 +459,7 @@ def test_reprojection_without_history_and_errors(tracer):
     s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
     W, H = 40, 24
     tracer.load_scene(s, sky); tracer.resize(W, H)
-    tracer.set_camera_history([])
+    tracer.clear_camera_history()
     plain = pa.make_params(s, W, H, seed=0.25, spp=1, max_bounces=4)
     tracer.render(plain); a = tracer.read_result()
     p2 = pa.make_params(s, W, H, seed=0.25, spp=1, max_bounces=4, render_mode=2, accumulation_frames=8)
@@ -470,7 +470,7 @@ def test_reprojection_without_history_and_errors(tracer):
     with pytest.raises(pa.PtraceError, match="accumulate"):
         tracer.render(bad)
     with pytest.raises(pa.PtraceError, match="renderMode"):
-        tracer.render(pa.make_params(s, W, H, render_mode=3))
+        tracer.render(pa.make_params(s, W, H, render_mode=9))
     # depth dispatch in renderMode 2: SH:799-809 returns before any reprojection
     d2 = pa.make_params(s, W, H, depth=1, render_mode=2)
     d1 = pa.make_params(s, W, H, depth=1)
@@ -617,6 +617,124 @@ def test_stripe_mode_errors(tracer):
                dict(divisions=4, counter=1, tile=(0, 0, 20, 10)), dict(divisions=4, counter=1, accumulate=pa.PT_ACCUM_MEAN)):
         with pytest.raises(pa.PtraceError):
             tracer.render(pa.make_params(s, W, H, render_mode=5, **kw))
+
+
+# ------------------------------------------- renderMode 3, 4, 10 (reprojection variants), 11 / 12 (pause), 7 / 8 (full-frame)
+
+@pytest.mark.parametrize("mode,kw", [(3, {}), (4, dict(left_eye=1)), (4, dict(left_eye=0)), (10, {})])
+def test_reprojection_variants_match_oracle_bit_exact(tracer, mode, kw):
+    """BlurAndReproj, StereoReproj (both eyes' offsets) and NewRender over three frames with a moving camera."""
+    from reproj_util import gpu_sequence, oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    # renderMode 4's hard-coded pixel offsets (156 / 538, made for a 2016-row eye texture) need a tall image to land on screen
+    W, H = ((320, 400) if kw["left_eye"] else (240, 1300)) if mode == 4 else (64, 36)
+    spp = 1 if mode == 10 else 2                                # the host sets 1 sample from mode 10 on (RayTracingMaster.cs:531)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_sequence(o, s, W, H, 3, spp=spp, max_bounces=4, frames_n=5, mode=mode, threads=8, **kw)
+    got = gpu_sequence(tracer, s, W, H, 3, spp=spp, max_bounces=4, frames_n=5, mode=mode, **kw)
+    plain_alpha = None
+    for k in range(3):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"Result1, frame {k}"
+        assert got[k][3]["rays"] == want[k][3]["rays"], k
+    # the history really is used: frame 2 differs from a plain render of the same frame in many pixels
+    from reproj_util import frame_params
+    p1, _ = frame_params(s, W, H, 2, spp, 4, 5, mode=1)
+    plain = o.render(p1, W, H, threads=8)[0]
+    changed = (np.abs(got[2][0][..., :3] - plain[..., :3]).max(-1) > 0).sum()
+    assert changed > (20 if mode == 4 else 500), changed
+    if mode == 10:
+        assert got[2][3]["rays"] < 0.8 * o.render(p1, W, H, threads=8)[2]["rays"]      # covered pixels trace no path
+
+
+def test_new_render_mode_several_samples(tracer):
+    """renderMode 10 with more than one sample (the host never asks for it, the shader allows it): the decision to
+    show the history is the same for every sample of a pixel, so the images agree; only the count of repeated
+    primary rays differs (the shader re-traces the covered pixels' camera rays)."""
+    from reproj_util import gpu_sequence, oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    W, H = 48, 27
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_sequence(o, s, W, H, 3, spp=3, max_bounces=4, frames_n=5, mode=10)
+    got = gpu_sequence(tracer, s, W, H, 3, spp=3, max_bounces=4, frames_n=5, mode=10)
+    for k in range(3):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert got[k][3]["rays"] <= want[k][3]["rays"]
+
+
+@pytest.mark.parametrize("mode", [11, 12])
+def test_pause_modes_match_oracle_bit_exact(tracer, mode):
+    """Two frames of renderMode 2, then three of PlanerPause / DepthPause with the camera moving on: the frozen frame
+    re-projected, bit for bit; Result1 and the history cameras stay as the last rendered frame left them."""
+    from reproj_util import gpu_pause_sequence, oracle_pause_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    W, H = 64, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_pause_sequence(o, s, W, H, 2, 3, mode)
+    got = gpu_pause_sequence(tracer, s, W, H, 2, 3, mode)
+    for k in range(5):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"Result1, frame {k}"
+        assert got[k][3]["rays"] == want[k][3]["rays"], k
+    assert (got[4][1] == got[2][1]).all()                                   # Result1 is not touched while paused
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "othermodes_64x36.npz"))
+    assert (got[4][0].view(np.uint32) == g[f"mode{mode}_result4"].view(np.uint32)).all()
+    assert (got[4][0][..., :3] > 0).mean() > 0.4 and not (got[4][0] == got[3][0]).all()
+    assert got[3][3]["rays"] == (0 if mode == 11 else W * H)
+
+
+def test_pause_mode_depth_and_errors(tracer):
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    W, H = 40, 24
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    tracer.render(pa.make_params(s, W, H, depth=1)); want = tracer.read_result()
+    tracer.render(pa.make_params(s, W, H, depth=1, render_mode=12))
+    assert (tracer.read_result().view(np.uint32) == want.view(np.uint32)).all()   # SH:799-809 comes before the pause block
+    with pytest.raises(pa.PtraceError, match="whole frames"):
+        tracer.render(pa.make_params(s, W, H, render_mode=11, tile=(0, 0, 20, 10)))
+    marker = np.full((H, W, 4), 0.375, np.float32)
+    tracer.write_target(pa.PT_TARGET_RESULT, marker)
+    tracer.render(pa.make_params(s, W, H, render_mode=11, spp=0))                  # the sample loop does not run: nothing written
+    assert (tracer.read_result() == marker).all()
+
+
+@pytest.mark.parametrize("mode", [7, 8])
+def test_full_frame_reproj_modes_match_oracle_bit_exact(tracer, mode):
+    """Ten frames, four stripes per cycle, moving camera: Result (the reprojected display), Result1 (the cycle's
+    reference frame) and Result2 (the frame being assembled) of every dispatch equal the oracle's."""
+    from reproj_util import gpu_stripe_sequence, oracle_stripe_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    W, H = 64, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_stripe_sequence(o, s, W, H, 10, 4, mode, spp=1, max_bounces=4)
+    got = gpu_stripe_sequence(tracer, s, W, H, 10, 4, mode, spp=1, max_bounces=4)
+    for k in range(10):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"Result1, frame {k}"
+        assert (got[k][4].view(np.uint32) == want[k][4].view(np.uint32)).all(), f"Result2, frame {k}"
+        assert got[k][3]["rays"] == want[k][3]["rays"] and got[k][3]["paths"] == want[k][3]["paths"], k
+    assert (got[9][0][..., :3] > 0).mean() > 0.5
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "othermodes_64x36.npz"))
+    assert (got[9][0].view(np.uint32) == g[f"mode{mode}_result9"].view(np.uint32)).all()
+    assert (got[9][4].view(np.uint32) == g[f"mode{mode}_result2_9"].view(np.uint32)).all()
+
+
+def test_full_frame_reproj_mesh_scene_uneven_rows_and_samples(tracer):
+    from reproj_util import gpu_stripe_sequence, oracle_stripe_sequence
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(256, 128)
+    W, H = 131, 77
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    for mode in (7, 8):
+        want = oracle_stripe_sequence(o, s, W, H, 12, 10, mode, spp=2, max_bounces=4, threads=8)
+        got = gpu_stripe_sequence(tracer, s, W, H, 12, 10, mode, spp=2, max_bounces=4)
+        for k in range(12):
+            for t, name in ((0, "Result"), (1, "Result1"), (4, "Result2")):
+                assert (got[k][t].view(np.uint32) == want[k][t].view(np.uint32)).all(), f"mode {mode} {name}, frame {k}"
 
 
 # ------------------------------------------- per-mesh materials and the GGX lobe (extensions)

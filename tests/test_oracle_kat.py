@@ -534,6 +534,158 @@ def test_stripe_modes_properties(mode):
     assert close[interior & (ids >= 0)].mean() > 0.8
 
 
+# ------------------------------------------- the remaining renderModes: 3, 4, 10, 11, 12, 7, 8
+
+def test_blur_and_new_render_modes_static_camera_properties():
+    """Static camera, so a hit pixel's history position is (about) the pixel itself.
+    renderMode 3 (SH:986-1019): colour = fresh/2.5 + bilinear/5 + four diagonal history texels/10, alpha = the new
+    distance.  renderMode 10 (SH:1048-1069): covered pixels copy the bilinear history sample - alpha too - and trace
+    no path; sky pixels and uncovered pixels are rendered as renderMode 1 renders them."""
+    from reproj_util import oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    W, H = 48, 27
+    plain = [o.render(pa.make_params(s, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4), W, H) for k in range(2)]
+    ids = plain[1][1]; hit = ids >= 0
+    seq3 = oracle_sequence(o, s, W, H, 2, spp=1, max_bounces=4, mode=3, step=(0, 0, 0))
+    assert (seq3[0][0] == plain[0][0]).all() and (seq3[1][1] == seq3[0][0]).all()       # no history yet; Result1 = Result
+    r = seq3[1][0]
+    assert (r[~hit] == plain[1][0][~hit]).all()
+    assert (r[..., 3] == plain[1][0][..., 3]).all()                                     # SH:1005: alpha is always the new distance
+    blended = hit & (np.abs(r[..., :3] - plain[1][0][..., :3]).max(-1) > 0)
+    assert blended.sum() > 0.5 * hit.sum()
+    # the weights sum to 1: the result stays within the range spanned by the fresh value and the history image
+    hi = np.maximum(plain[1][0][..., :3], seq3[0][0][..., :3].max()) + 1e-6
+    assert (r[..., :3][blended] <= np.broadcast_to(hi, r[..., :3].shape)[blended]).all()
+
+    seq10 = oracle_sequence(o, s, W, H, 2, spp=1, max_bounces=4, mode=10, step=(0, 0, 0))
+    assert (seq10[0][0] == plain[0][0]).all()                                           # nothing to copy from: a plain render
+    r, r1, _, st = seq10[1]
+    assert (r1 == seq10[0][0]).all()
+    assert (r[~hit] == plain[1][0][~hit]).all()                                         # !skyboxS fails: traced
+    covered = hit & (r != plain[1][0]).any(-1)
+    assert covered.sum() > 0.5 * hit.sum()
+    assert st["rays"] < plain[1][2]["rays"] and st["rays"] >= W * H                     # one primary ray each, paths only where uncovered
+    traced = hit & ~covered
+    assert (r[traced] == plain[1][0][traced]).all()
+
+
+def test_stereo_reproj_mode_offsets():
+    """renderMode 4 (SH:1021-1046) finds the history position with FindCameraRayVR (SH:418-437): its per-eye offsets
+    (156 / 538 pixels) put every position off screen in a small image, which leaves the plain render; in a tall image
+    the two eyes blend different pixels."""
+    from reproj_util import oracle_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    W, H = 48, 27
+    seq = oracle_sequence(o, s, W, H, 2, spp=1, max_bounces=4, mode=4, step=(0, 0, 0), left_eye=1)
+    plain = o.render(pa.make_params(s, W, H, seed=pa.frame_seed(1), spp=1, max_bounces=4), W, H)[0]
+    assert (seq[1][0] == plain).all()
+    W, H = 160, 400
+    out = {}
+    for eye in (0, 1):
+        seq = oracle_sequence(o, s, W, H, 2, spp=1, max_bounces=4, mode=4, step=(0, 0, 0), left_eye=eye, threads=8)
+        plain = o.render(pa.make_params(s, W, H, seed=pa.frame_seed(1), spp=1, max_bounces=4), W, H, threads=8)[0]
+        out[eye] = (seq[1][0] != plain).any(-1)
+    assert out[1].sum() > 100 and not (out[0] == out[1]).all()
+
+
+@pytest.mark.parametrize("mode", [11, 12])
+def test_pause_modes_properties(mode):
+    """renderMode 11 / 12 (SH:1071-1104): nothing is path-traced, Result1 is not written, and with the camera where the
+    history camera was a pixel shows (a bilinear tap of) Result1 around its own position - or (0,0,0,1) where the depth
+    variant's primary ray misses."""
+    from reproj_util import oracle_pause_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    W, H = 48, 27
+    seq = oracle_pause_sequence(o, s, W, H, 2, 2, mode, step=(0, 0, 0))
+    frozen = seq[1][1]                                   # Result1 after the last rendered frame
+    for k in (2, 3):
+        res, res1, ids, st = seq[k]
+        assert (res1 == frozen).all()
+        assert st["rays"] == (0 if mode == 11 else W * H)
+        assert (res == seq[2][0]).all()                  # no randomness, no state: every paused frame is the same
+    res, ids = seq[2][0], seq[2][2]
+    if mode == 12:
+        assert (res[ids < 0] == np.array([0, 0, 0, 1], np.float32)).all()
+        on = ids >= 0
+    else:
+        on = np.ones((H, W), bool)
+    interior = np.zeros((H, W), bool); interior[2:-2, 2:-2] = True
+    lo = np.minimum.reduce([np.roll(frozen, (dy, dx), (0, 1)) for dy in (0, 1, 2) for dx in (0, 1, 2)])
+    hi = np.maximum.reduce([np.roll(frozen, (dy, dx), (0, 1)) for dy in (0, 1, 2) for dx in (0, 1, 2)])
+    sel = interior & on
+    inside = ((res >= lo - 1e-5) & (res <= hi + 1e-5)).all(-1)
+    assert inside[sel].mean() > 0.95                     # a bilinear tap lies between the texels it reads
+
+
+@pytest.mark.parametrize("mode", [7, 8])
+def test_full_frame_reproj_modes_properties(mode):
+    """renderMode 7 / 8 (SH:751-789, 850-853, 938-948) with a static camera and 4 stripes: the dispatch with counter 0
+    renders the whole frame (from "history camera -1", the current one) into Result2 and copies it to Result1 and
+    Result; the following dispatches re-render one stripe each into Result2, show Result1 reprojected in Result and
+    leave Result1 alone."""
+    from reproj_util import oracle_stripe_sequence, stripe_frames
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    o = po.Oracle.from_scene(s, sky, accel=True)
+    W, H, D = 48, 40, 4
+    seq = oracle_stripe_sequence(o, s, W, H, D + 1, D, mode, step=(0, 0, 0))
+    frames = stripe_frames(s, W, H, D + 1, D, mode, step=(0, 0, 0))
+    stripe = H / D
+    p1 = pa.PtFrameParams.from_buffer_copy(frames[0][0]); p1.render_mode = 1
+    plain0, ids0, st0 = o.render(p1, W, H)
+    sky_px = ids0 < 0
+    res, res1, _, st, res2 = seq[0]
+    keep = ~sky_px if mode == 8 else np.ones((H, W), bool)           # mode 8: a primary miss returns at SH:760-763
+    assert (res2[keep] == plain0[keep]).all() and (res1[keep] == plain0[keep]).all() and (res[keep] == plain0[keep]).all()
+    if mode == 8:
+        assert (res2[sky_px] == 0).all() and (res[sky_px][:, 3] == 1.0).all() and (res[sky_px][:, :3] > 0).any()
+    for k in range(1, D):
+        res, r1k, _, st, r2k = seq[k]
+        assert (r1k == res1).all()                                   # Result1 only changes when counter is 0
+        rows = [y for y in range(H) if not (y > H - stripe * k or y < H - stripe * (k + 1))]
+        others = [y for y in range(H) if y not in rows]
+        assert (r2k[others] == seq[k - 1][4][others]).all()          # Result2: only the stripe is re-rendered
+        pk = pa.PtFrameParams.from_buffer_copy(frames[k][0]); pk.render_mode = 1
+        plain_k = o.render(pk, W, H)[0]
+        sel = np.zeros((H, W), bool); sel[rows] = True; sel &= keep
+        assert (r2k[sel] == plain_k[sel]).all()                      # same camera: the stripe is what renderMode 1 renders
+        n_stripe = len(rows) * W - (int((sky_px[rows]).sum()) if mode == 8 else 0)
+        assert st["paths"] == n_stripe + (W * H if mode == 8 else 0)
+    # the first dispatch of the next cycle publishes the assembled frame
+    res, r1n, _, _, r2n = seq[D]
+    assert (r1n[keep] == r2n[keep]).all() and (res[keep] == r2n[keep]).all()
+
+
+def test_camera_ray_old_matches_camera_ray_for_a_perspective_camera():
+    """CreateCameraRayOld (SH:374-387) feeds clip z = 1 where CreateCameraRay (SH:108-120) feeds 0; the inverse of a
+    perspective projection has an empty third column in its xyz rows, so renderMode 7's first dispatch - history
+    element -1, the current camera - renders exactly what renderMode 1 renders (checked above); here the matrix itself."""
+    s = pa.Scene("fixture")
+    p = pa.make_params(s, 64, 36)
+    ip = np.array(p.camera_inverse_projection[:], np.float32).reshape(4, 4).T      # [row, col]
+    assert (ip[:3, 2] == 0).all() and ip[3, 2] != 0
+
+
+def test_other_modes_golden():
+    from reproj_util import oracle_pause_sequence, oracle_sequence, oracle_stripe_sequence
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "othermodes_64x36.npz"))
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    o = po.Oracle.from_scene(s, sky)
+    W, H = 64, 36
+    for mode, spp in ((3, 2), (10, 1)):
+        got = oracle_sequence(o, s, W, H, 3, spp=spp, max_bounces=4, frames_n=5, mode=mode)[2][0]
+        assert (got.view(np.uint32) == g[f"mode{mode}_result2"].view(np.uint32)).all(), mode
+    for mode in (11, 12):
+        got = oracle_pause_sequence(o, s, W, H, 2, 3, mode)[4][0]
+        assert (got.view(np.uint32) == g[f"mode{mode}_result4"].view(np.uint32)).all(), mode
+    for mode in (7, 8):
+        seq = oracle_stripe_sequence(o, s, W, H, 10, 4, mode, spp=1, max_bounces=4)
+        assert (seq[9][0].view(np.uint32) == g[f"mode{mode}_result9"].view(np.uint32)).all(), mode
+        assert (seq[9][4].view(np.uint32) == g[f"mode{mode}_result2_9"].view(np.uint32)).all(), mode
+
+
 # ------------------------------------------- per-mesh materials and the GGX lobe (extensions)
 
 def _one_quad_scene(material):

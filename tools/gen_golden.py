@@ -74,3 +74,19 @@ for mode in (5, 6):
     st[f"mode{mode}_result5"] = seqs[5][0]; st[f"mode{mode}_result1_5"] = seqs[5][1]
 np.savez_compressed(os.path.join(out, "stripes_64x36.npz"), **st)
 print("wrote stripes_64x36.npz")
+
+# (xi) the remaining renderModes on the same scene: 3 and 10 (three frames, moving camera; last frame), 11 and 12 (two
+# rendered frames, three paused; last frame), 7 and 8 (ten frames, 4 stripes per cycle; last frame's Result and Result2).
+# renderMode 4 needs a tall image for its hard-coded offsets to land on screen and is covered by the parity tests only.
+from reproj_util import oracle_pause_sequence  # noqa: E402
+
+om = {}
+for mode, spp in ((3, 2), (10, 1)):
+    om[f"mode{mode}_result2"] = oracle_sequence(o, s, W, H, 3, spp=spp, max_bounces=4, frames_n=5, mode=mode)[2][0]
+for mode in (11, 12):
+    om[f"mode{mode}_result4"] = oracle_pause_sequence(o, s, W, H, 2, 3, mode)[4][0]
+for mode in (7, 8):
+    seqs = oracle_stripe_sequence(o, s, W, H, 10, 4, mode, spp=1, max_bounces=4)
+    om[f"mode{mode}_result9"] = seqs[9][0]; om[f"mode{mode}_result2_9"] = seqs[9][4]
+np.savez_compressed(os.path.join(out, "othermodes_64x36.npz"), **om)
+print("wrote othermodes_64x36.npz", {k: float(v[..., :3].mean()) for k, v in om.items()})
