@@ -329,10 +329,11 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
     hist_entry = [pa.camera_history_entry(cam(k), scene.target, scene.fov, W / H) for k in range(n_total)]
 
     def run(mode):
-        prm = [pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k), render_mode=mode,
-                              accumulation_frames=10) for k in range(n_total)]
+        # the pause modes (11 / 12) follow three frames of renderMode 2 and upload no cameras (RayTracingMaster.cs:513-526)
+        prm = [pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, eye=cam(k),
+                              render_mode=2 if (mode >= 11 and k < 3) else mode, accumulation_frames=10) for k in range(n_total)]
         def frame(k):
-            if mode != 1:
+            if mode != 1 and (mode < 11 or k <= 3):
                 t.set_camera_history([hist_entry[k - 1]] if k else [])
             t.render(prm[k])
         t.clear_camera_history()
@@ -373,12 +374,17 @@ def reproj_frame_time(pa, torch, scene, sky, frames=30):
     shown = t.read_result()
     ms5 = run_stripes(5)
     ms6 = run_stripes(6)
+    others = {f"mode{m}": run(m) for m in (3, 10, 11, 12)}
+    others.update({f"mode{m}": run_stripes(m) for m in (7, 8)})
     t.close()
     return {"ms_per_frame": ms2, "plain_ms_per_frame": plain, "denoise_mode_ms_per_frame": ms0,
             "stripes_ms_per_frame": ms5, "stripes_depth_ms_per_frame": ms6, "frames": frames,
+            "other_modes_ms_per_frame": others,
             "denoise_mode_image_mean": float(shown[..., :3].mean()),
             "config": "bench scene, 1920x1080, 1 spp, 4 bounces, _AccumulationFrames 10, 1 GPU; renderMode 2 / 1 / 0; "
-                      "renderMode 5 / 6 with 10 stripes (one path-traced per frame, the others reprojected)"}
+                      "renderMode 5 / 6 with 10 stripes (one path-traced per frame, the others reprojected); other_modes: 3 (blur), "
+                      "10 (paths only where the history has nothing), 11 / 12 (pause: reprojection only), 7 / 8 (10 stripes into "
+                      "Result2, every pixel reprojected; every tenth frame renders the whole image)"}
 
 
 if __name__ == "__main__":

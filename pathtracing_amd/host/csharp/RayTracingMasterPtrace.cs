@@ -27,7 +27,7 @@ public class RayTracingMasterPtrace : MonoBehaviour
         public float seed; public int samples_per_pixel; public int max_bounces; public int depth; public int render_mode;
         public uint sample_index; public int accumulate; public int tile_x0, tile_y0, tile_w, tile_h;
         public fixed float pixel_offset[2]; public fixed float directional_light[4];
-        public int accumulation_frames;
+        public int accumulation_frames, divisions, counter, left_eye;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -48,7 +48,8 @@ public class RayTracingMasterPtrace : MonoBehaviour
 
     public int SphereSeed; public Vector2 SphereRadius = new Vector2(3.0f, 8.0f); public uint SpheresMax = 100; public float SpherePlacementRadius = 100.0f;
     public int samplesPerPixel = 1; public uint sampleFrames = 3; public bool depth = false;
-    public int renderMode = 1;                                // RenderMode.Default = 1, RenderMode.Reproj = 2 (:977-990)
+    public int renderMode = 1;                                // every value of RenderMode (:977-990) is implemented
+    int divisions = 10, counter = 0;                          // :701-702
     readonly List<PtCameraHistory> _oldCameras = new List<PtCameraHistory>();   // oldIPR / oldCTW / oldWTC / oldPRJ, :450-453
 
     IntPtr _ctx; Camera _camera; uint _currentSample; int _width, _height; bool _geometryUploaded;
@@ -111,14 +112,16 @@ public class RayTracingMasterPtrace : MonoBehaviour
         Matrix4x4 c2w = _camera.cameraToWorldMatrix, ip = _camera.projectionMatrix.inverse;                       // :489-490
         for (int i = 0; i < 16; i++) { p.camera_to_world[i] = c2w[i]; p.camera_inverse_projection[i] = ip[i]; }  // Matrix4x4[i] is column-major
         p.seed = UnityEngine.Random.value;                     // :530
-        p.samples_per_pixel = samplesPerPixel;                 // :531
+        p.samples_per_pixel = renderMode < 10 ? samplesPerPixel : 1;   // :531
         p.max_bounces = 4;                                     // the shader's loop bound, RayTracingShader.compute:867
         p.depth = depth ? 1 : 0;                               // :532
         p.render_mode = renderMode;                            // :735
         p.accumulation_frames = (int)sampleFrames;             // :738
+        p.divisions = divisions; p.counter = counter++ % divisions;   // :736-737
+        p.left_eye = _camera.stereoTargetEye == StereoTargetEyeMask.Left ? 1 : 0;   // :460-462
         p.accumulate = (depth || renderMode != 1) ? 0 : 3;     // AddMat.shader blend; in Reproj mode _converged is the history
         Check(pt_set_camera_history(_ctx, _oldCameras.ToArray(), _oldCameras.Count), "pt_set_camera_history");   // :492-495
-        if (renderMode < 5 || renderMode > 8) _oldCameras.Clear();                                               // :513-518
+        if (renderMode < 5 || renderMode > 8 || p.counter == 0) _oldCameras.Clear();                             // :513-518
         if (renderMode < 11 && renderMode != 1)                                                                  // :520-526
             _oldCameras.Add(new PtCameraHistory { cameraToWorld = c2w, cameraInverseProjection = ip, worldToCamera = _camera.worldToCameraMatrix, cameraProjection = _camera.projectionMatrix });
         p.sample_index = depth ? 0u : _currentSample;          // :805

@@ -116,6 +116,7 @@ void RayTracingMaster::FillParams(PtFrameParams &p) const
     p.accumulation_frames = (int32_t)sampleFrames;        // :738
     p.divisions = divisions;                              // :736
     p.counter = divisions > 0 ? counter_ % divisions : 0; // :737 (the increment happens in Render)
+    p.left_eye = eyeOffset < 0.0f ? 1 : 0;                // :460-462 (_leftEye; read by renderMode 4 only)
 }
 
 int RayTracingMaster::SetShaderParameters(PtFrameParams &p)

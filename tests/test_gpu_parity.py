@@ -865,3 +865,51 @@ def test_master_mirror_partial_frame_mode_cycles_the_counter():
         assert counters == [0, 1, 2, 3, 0, 1, 2, 3, 0]
     finally:
         lib.ptm_master_destroy(h)
+
+
+def test_master_mirror_switches_through_every_render_mode():
+    """The C++ RayTracingMaster mirror driven through the host's mode keys (RayTracingMaster.cs:177-212) while the
+    camera moves: Reproj, BlurAndReproj, NewRender (one sample, :531), DepthPause (empty camera lists, :513-526),
+    FullFrameReprojDepth across a cycle boundary, Denoise.  The counter runs on in every mode (:737).  The oracle is
+    fed the parameters the mirror uploads and a Python restatement of the list handling."""
+    import ctypes as C
+    from pathtracing_amd import _ffi
+    lib = _ffi.ptmaster()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        W, H, D = 64, 36, 4
+        assert lib.ptm_master_load_scene(h, s.handle, 128, 64) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, W, H, 2, 4, 0, pa.PT_ACCUM_NONE, 6)
+        lib.ptm_master_set_divisions(h, D)
+        orc = po.Oracle.from_scene(s, pa.procedural_sky(128, 64), accel=False)
+        ctx = lib.ptm_master_context(h)
+        res = np.zeros((H, W, 4), np.float32); res1 = np.zeros((H, W, 4), np.float32); res2 = np.zeros((H, W, 4), np.float32)
+        state = [pa.PtCameraHistory() for _ in range(100)]
+        old = []
+        modes = [2, 2, 3, 10, 12, 12, 8, 8, 8, 8, 8, 8, 0, 0]
+        for k, mode in enumerate(modes):
+            lib.ptm_master_set_render_mode(h, mode)
+            eye = (s.eye[0] + 0.1 * k, s.eye[1], s.eye[2] + 0.15 * k)
+            lib.ptm_master_set_camera(h, (C.c_float * 3)(*eye), (C.c_float * 3)(*s.target), C.c_float(s.fov), C.c_float(0.0))
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            assert p.render_mode == mode and p.counter == k % D
+            assert p.samples_per_pixel == (2 if mode < 10 else 1)
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            state[:len(old)] = old
+            orc.render_history(p, state, W, H, res, res1, threads=4, result2=res2)
+            if mode < 5 or mode > 8 or p.counter == 0:
+                old = []
+            if mode < 11 and mode != 1:
+                old.append(pa.camera_history_entry(eye, s.target, s.fov, W / H))
+            got = np.empty((H, W, 4), np.float32)
+            assert _ffi.ptrace().pt_read_result(ctx, got.ctypes.data) == 0
+            _assert_same_image(got, res, f"frame {k} (mode {mode}) Result")
+            assert _ffi.ptrace().pt_read_converged(ctx, got.ctypes.data) == 0
+            _assert_same_image(got, res1, f"frame {k} (mode {mode}) Result1")
+            assert _ffi.ptrace().pt_read_target(ctx, pa.PT_TARGET_DENOISED, got.ctypes.data) == 0
+            _assert_same_image(got, res2, f"frame {k} (mode {mode}) Result2")
+    finally:
+        lib.ptm_master_destroy(h)
