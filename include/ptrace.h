@@ -309,6 +309,24 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays,
 
 const char *pt_version(void);
 
+/* Several devices from one host thread.  The reference's host is a single Unity process
+ * (RayTracingMaster.cs drives one ComputeShader per eye camera, :47-52 share the scene lists between
+ * them); a group gives such a host one context per device: pt_group_create makes them, the caller
+ * uploads the scene to each (pt_group_context(i) + the pt_set_* calls) and splits the work by eye, by
+ * sample index (accumulate = PT_ACCUM_SUM, one _Seed per sample index) or by rows (tile_*), and
+ * pt_group_reduce adds every member's converged target into the root's, member by member in index
+ * order (so the float sum is reproducible), ordered after the renders issued so far on each member and
+ * before any later render of a member overwrites its image; the call itself does not wait.  Eye and
+ * row splits need no reduce.  No counterpart in the reference, which renders on one GPU.  Processes that own one
+ * device each use their own communication layer instead (bench.py: torch.distributed over RCCL). */
+typedef struct pt_group pt_group;
+int pt_group_create(int n, const int *device_ordinals, pt_group **out_group);
+void pt_group_destroy(pt_group *group);
+int pt_group_size(const pt_group *group);
+pt_context *pt_group_context(pt_group *group, int index);
+int pt_group_reduce(pt_group *group, int root);
+const char *pt_group_last_error(const pt_group *group);
+
 #ifdef __cplusplus
 }
 #endif

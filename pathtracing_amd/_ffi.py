@@ -83,6 +83,12 @@ PTRACE_SYMBOLS = {
     "pt_get_stats": (C.c_int, [_ctx, _P(PtStats)]),
     "pt_trace_rays": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pt_version": (C.c_char_p, []),
+    "pt_group_create": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_void_p)]),
+    "pt_group_destroy": (None, [C.c_void_p]),
+    "pt_group_size": (C.c_int, [C.c_void_p]),
+    "pt_group_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "pt_group_reduce": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_group_last_error": (C.c_char_p, [C.c_void_p]),
 }
 
 PTMASTER_SYMBOLS = {

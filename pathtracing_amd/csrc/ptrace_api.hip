@@ -101,6 +101,29 @@ struct pt_context {
     size_t wf_iters = 0;
 };
 
+// Several contexts, one per device, driven by one host thread (a Unity host is one process): the scene is replicated,
+// each member renders its share of the eyes / sample indices / rows, and pt_group_reduce adds the members' converged
+// images up on one of them.
+struct pt_group {
+    std::vector<pt_context *> members;
+    std::vector<hipEvent_t> ready;     // member i's renders so far are complete (recorded on its stream)
+    hipEvent_t taken = nullptr;        // the root has finished reading the members' images
+    float4 *staging = nullptr;         // on the root's device
+    size_t staging_pixels = 0;
+    int staging_device = -1;
+    std::string err;
+};
+
+namespace ptrace {
+__global__ __launch_bounds__(256) void add_image_kernel(float4 *dst, const float4 *src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+}  // namespace ptrace
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -1096,6 +1119,108 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
         return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
     }
     cleanup();
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------- device groups
+
+int pt_group_create(int n, const int *device_ordinals, pt_group **out_group)
+{
+    if (!out_group) return fail(nullptr, PT_ERR_INVALID, "pt_group_create: out_group is NULL");
+    *out_group = nullptr;
+    if (n < 1 || n > 64 || !device_ordinals) return fail(nullptr, PT_ERR_INVALID, "pt_group_create: need 1..64 device ordinals");
+    pt_group *g = new (std::nothrow) pt_group();
+    if (!g) return fail(nullptr, PT_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < n; i++) {
+        pt_context *c = nullptr;
+        int rc = pt_create(device_ordinals[i], &c);
+        hipEvent_t ev = nullptr;
+        if (rc == PT_OK) {
+            DeviceGuard dg(device_ordinals[i]);
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) { g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e); pt_destroy(c); rc = PT_ERR_HIP; }
+        }
+        if (rc != PT_OK) { pt_group_destroy(g); return rc; }      // g_create_error holds the reason
+        g->members.push_back(c); g->ready.push_back(ev);
+    }
+    *out_group = g;
+    return PT_OK;
+}
+
+void pt_group_destroy(pt_group *g)
+{
+    if (!g) return;
+    if (g->staging) { DeviceGuard dg(g->staging_device); (void)hipFree(g->staging); }
+    if (g->taken) { DeviceGuard dg(g->staging_device); (void)hipEventDestroy(g->taken); }
+    for (size_t i = 0; i < g->members.size(); i++) {
+        if (g->ready[i]) { DeviceGuard dg(g->members[i]->device); (void)hipEventDestroy(g->ready[i]); }
+        pt_destroy(g->members[i]);
+    }
+    delete g;
+}
+
+int pt_group_size(const pt_group *g) { return g ? (int)g->members.size() : 0; }
+
+pt_context *pt_group_context(pt_group *g, int index)
+{
+    return g && index >= 0 && index < (int)g->members.size() ? g->members[(size_t)index] : nullptr;
+}
+
+const char *pt_group_last_error(const pt_group *g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+
+int pt_group_reduce(pt_group *g, int root)
+{
+    if (!g) return PT_ERR_INVALID;
+    auto gfail = [&](int code, const std::string &msg) { g->err = msg; return code; };
+    const int n = (int)g->members.size();
+    if (root < 0 || root >= n) return gfail(PT_ERR_INVALID, "pt_group_reduce: root is not a member index");
+    pt_context *r = g->members[(size_t)root];
+    if (r->W == 0) return gfail(PT_ERR_INVALID, "pt_group_reduce before pt_resize");
+    for (pt_context *c : g->members)
+        if (c->W != r->W || c->H != r->H) return gfail(PT_ERR_INVALID, "pt_group_reduce: the members' image sizes differ");
+    if (n == 1) return PT_OK;
+    const size_t pixels = (size_t)r->W * r->H, bytes = pixels * sizeof(float4);
+#define PT_GHIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return gfail(e_ == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    // every member marks the end of its renders so far
+    for (int i = 0; i < n; i++) {
+        if (i == root) continue;
+        DeviceGuard dg(g->members[(size_t)i]->device);
+        PT_GHIP(hipEventRecord(g->ready[(size_t)i], g->members[(size_t)i]->stream));
+    }
+    {
+        DeviceGuard dg(r->device);
+        if (g->staging_pixels < pixels || g->staging_device != r->device) {
+            PT_GHIP(hipStreamSynchronize(r->stream));
+            if (g->staging) { DeviceGuard old(g->staging_device); (void)hipFree(g->staging); g->staging = nullptr; }
+            if (g->taken) { DeviceGuard old(g->staging_device); (void)hipEventDestroy(g->taken); g->taken = nullptr; }
+            g->staging_pixels = 0;
+            PT_GHIP(hipMalloc((void **)&g->staging, bytes));
+            PT_GHIP(hipEventCreateWithFlags(&g->taken, hipEventDisableTiming));
+            g->staging_pixels = pixels; g->staging_device = r->device;
+        }
+        // members in index order, each image copied over the fabric into the staging buffer and added: a fixed order,
+        // so the sum is reproducible from run to run
+        for (int i = 0; i < n; i++) {
+            if (i == root) continue;
+            pt_context *c = g->members[(size_t)i];
+            PT_GHIP(hipStreamWaitEvent(r->stream, g->ready[(size_t)i], 0));
+            PT_GHIP(hipMemcpyPeerAsync(g->staging, r->device, c->conv, c->device, bytes, r->stream));
+            hipLaunchKernelGGL(ptrace::add_image_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, r->stream, r->conv, g->staging, pixels);
+            PT_GHIP(hipGetLastError());
+        }
+        PT_GHIP(hipEventRecord(g->taken, r->stream));
+    }
+    // a member's next render may overwrite its image: it waits until the root has read it
+    for (int i = 0; i < n; i++) {
+        if (i == root) continue;
+        DeviceGuard dg(g->members[(size_t)i]->device);
+        PT_GHIP(hipStreamWaitEvent(g->members[(size_t)i]->stream, g->taken, 0));
+    }
+#undef PT_GHIP
     return PT_OK;
 }
 

@@ -12,15 +12,19 @@ class PtraceError(RuntimeError):
 
 
 class PathTracer:
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed_ctx=None):
         self._lib = _ffi.ptrace()
+        self._owned = _borrowed_ctx is None
+        self.width = self.height = 0
+        if not self._owned:                      # a member of a PathTracerGroup: the group destroys it
+            self._ctx = C.c_void_p(_borrowed_ctx)
+            return
         self._ctx = C.c_void_p()
         rc = self._lib.pt_create(int(device), C.byref(self._ctx))
         if rc != 0:
             msg = self._lib.pt_last_error(None).decode()
             self._ctx = None
             raise PtraceError(f"pt_create({device}) failed ({rc}): {msg}")
-        self.width = self.height = 0
 
     def _check(self, rc, what):
         if rc != 0:
@@ -28,7 +32,8 @@ class PathTracer:
 
     def close(self):
         if getattr(self, "_ctx", None):
-            self._lib.pt_destroy(self._ctx)
+            if self._owned:
+                self._lib.pt_destroy(self._ctx)
             self._ctx = None
 
     def __del__(self):
@@ -159,3 +164,43 @@ class PathTracer:
         self._check(self._lib.pt_trace_rays(self._ctx, od.ctypes.data, len(od), int(bool(brute_force)),
                                             ids.ctypes.data, ts.ctypes.data), "pt_trace_rays")
         return ids, ts
+
+
+class PathTracerGroup:
+    """pt_group_*: one context per listed device, driven from this thread; `members[i]` is a PathTracer."""
+
+    def __init__(self, devices):
+        self._lib = _ffi.ptrace()
+        self._grp = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.pt_group_create(len(devices), arr, C.byref(self._grp))
+        if rc != 0:
+            msg = self._lib.pt_group_last_error(None).decode()
+            self._grp = None
+            raise PtraceError(f"pt_group_create({list(devices)}) failed ({rc}): {msg}")
+        self.members = [PathTracer(_borrowed_ctx=self._lib.pt_group_context(self._grp, i))
+                        for i in range(self._lib.pt_group_size(self._grp))]
+
+    def reduce(self, root=0):
+        rc = self._lib.pt_group_reduce(self._grp, int(root))
+        if rc != 0:
+            raise PtraceError(f"pt_group_reduce failed ({rc}): {self._lib.pt_group_last_error(self._grp).decode()}")
+
+    def close(self):
+        if getattr(self, "_grp", None):
+            for m in self.members:
+                m.close()
+            self._lib.pt_group_destroy(self._grp)
+            self._grp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -913,3 +913,43 @@ def test_master_mirror_switches_through_every_render_mode():
             _assert_same_image(got, res2, f"frame {k} (mode {mode}) Result2")
     finally:
         lib.ptm_master_destroy(h)
+
+
+def test_group_reduce_adds_the_members_images_in_index_order(sky_small):
+    """pt_group_*: three contexts (all on device 0 here; one per GPU in use) each add their share of six sample
+    indices into their own converged image (PT_ACCUM_SUM); the reduce leaves (member0 + member1) + member2 on the
+    root, bit for bit, and the members' next renders are ordered after it."""
+    W, H = 64, 36
+    fixture_scene = pa.Scene("fixture")
+    with pa.PathTracerGroup([0, 0, 0]) as grp:
+        assert len(grp.members) == 3
+        for m in grp.members:
+            m.load_scene(fixture_scene, sky_small); m.resize(W, H)
+        for k in range(6):
+            m = grp.members[k % 3]
+            m.render(pa.make_params(fixture_scene, W, H, seed=pa.frame_seed(k), spp=2, max_bounces=4,
+                                    accumulate=pa.PT_ACCUM_SUM, sample_index=k // 3))
+        parts = [m.read_converged() for m in grp.members]
+        grp.reduce(root=0)
+        # the members go on rendering straight away; member 1 overwrites its image (sample_index 0 restarts the sum)
+        grp.members[1].render(pa.make_params(fixture_scene, W, H, seed=0.125, spp=1, max_bounces=4,
+                                             accumulate=pa.PT_ACCUM_SUM, sample_index=0))
+        total = grp.members[0].read_converged()
+        want = (parts[0] + parts[1]) + parts[2]
+        assert (total.view(np.uint32) == want.view(np.uint32)).all()
+        assert (grp.members[2].read_converged() == parts[2]).all()            # the other members keep theirs
+        # against one context taking all six samples: the same image up to float summation order
+        with pa.PathTracer(0) as one:
+            one.load_scene(fixture_scene, sky_small); one.resize(W, H)
+            for k in range(6):
+                one.render(pa.make_params(fixture_scene, W, H, seed=pa.frame_seed(k), spp=2, max_bounces=4,
+                                          accumulate=pa.PT_ACCUM_SUM, sample_index=k))
+            ref = one.read_converged()
+        assert np.allclose(total, ref, rtol=1e-5, atol=1e-5)
+        with pytest.raises(pa.PtraceError, match="root"):
+            grp.reduce(root=3)
+        grp.members[2].resize(32, 18)
+        with pytest.raises(pa.PtraceError, match="sizes differ"):
+            grp.reduce(root=0)
+    with pytest.raises(pa.PtraceError, match="ordinal"):
+        pa.PathTracerGroup([0, 4096])
