@@ -88,6 +88,22 @@ def cpu_baseline(scene, sky, args):
     return out
 
 
+# Arithmetic per unit of work, counted from the kernel source (one fused multiply-add = 2 flops; conversions, selects and
+# integer work not counted): a four-child node visit = 24 plane FMAs + 6 FMAs/multiplies of set-up + 4 x (5 min/max +
+# 1 multiply + 2 compares); a primitive test = Moller-Trumbore (two cross products, four dot products, one divide);
+# Shade() + ray set-up per ray ~ 150.
+FLOPS_PER_NODE, FLOPS_PER_PRIM, FLOPS_PER_RAY = 48 + 9 + 32, 45, 150
+VALU_PEAK_TFLOPS = 157.3
+
+
+def valu_view(solo, launches, kernel_ms):
+    flops = (solo["nodes_visited"] * FLOPS_PER_NODE + solo["prims_tested"] * FLOPS_PER_PRIM + solo["rays"] * FLOPS_PER_RAY) / launches
+    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    return {"achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS,
+            "flops_per_ray": flops * launches / max(1, solo["rays"]),
+            "note": "counted useful flops; the VALU itself is busy about half of the time at 45 % of lanes (profiles/)"}
+
+
 def measured_traffic(args):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes, when they were
     taken on this workload; None otherwise (bench.py cannot run the profiler on itself)."""
@@ -220,7 +236,9 @@ def main():
                          "bytes_per_ray": (solo["nodes_visited"] * NODE_BYTES + solo["prims_tested"] * PRIM_BYTES) / max(1, r_rank),
                          "nodes_per_ray": solo["nodes_visited"] / max(1, r_rank),
                          "prims_per_ray": solo["prims_tested"] / max(1, r_rank),
-                         "kernel_mrays_per_s": r_rank / solo_launches / (kernel_ms * 1e-3) / 1e6},
+                         "kernel_mrays_per_s": r_rank / solo_launches / (kernel_ms * 1e-3) / 1e6,
+                         # the other roofline the kernel could sit under: counted arithmetic against the fp32 vector peak
+                         "valu": valu_view(solo, solo_launches, kernel_ms)},
             "image_mean_rgb": [float(x) for x in img[..., :3].reshape(-1, 3).mean(axis=0)],
             "image_crc": int(np.bitwise_xor.reduce(np.ascontiguousarray(img).view(np.uint32).reshape(-1))),
             "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
