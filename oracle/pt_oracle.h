@@ -1,9 +1,9 @@
 /*
  * pt_oracle.h - CPU oracle for libptrace.  TEST INFRASTRUCTURE ONLY.
  *
- * A scalar restatement, in plain C, of the plain path-trace mode, the
- * temporal-reprojection mode and the denoise mode (renderMode 1, 2 and 0) of
- * Assets/Scripts/RayTracingShader.compute (kernel CSMain) and of
+ * A scalar restatement, in plain C, of kernel CSMain of
+ * Assets/Scripts/RayTracingShader.compute in every renderMode the host can
+ * select (RayTracingMaster.cs:977-990), of Assets/Shaders/Denoiser.shader and of
  * Assets/Shaders/AddMat.shader, written line by line from those files.  It is
  * the checker the HIP kernels are compared with; nothing in the product links
  * or calls it.  Only tests/, __graft_entry__.smoke() and bench.py's
@@ -58,7 +58,11 @@ void pto_release(PtoPrepared *p);
 int pto_render(const PtoPrepared *p, const PtFrameParams *params, int width, int height,
                float *result, int32_t *hit_ids, PtoStats *stats, int threads);
 
-/* The same for renderMode 0, 1 or 2.
+/* The same for every renderMode (0 .. 8, 10, 11, 12); `history` = the four *Old camera arrays, elements
+ * n_history .. 99 zero.  renderMode 3, 4 and 10 treat `result` / `result1` as renderMode 2 does; 5 / 6 copy the
+ * rendered stripe into `result1` last; 7 / 8 write their stripe to `result2` and, when counter is 0, copy the
+ * finished pixels of `result2` to `result1` and `result` once every read of `result1` is done; 11 / 12 leave
+ * `result1` alone.  Reads of Result1 always see it as it was when the dispatch started (after the prologue copy).
  * renderMode 2 (RayTracingShader.compute:728-731,950-983): `result` holds the previous frame on entry;
  * `result1` (W*H*4) first receives a copy of it over the dispatched rectangle - the whole copy before any
  * pixel is traced - and is the history the pixels reproject from; history[0] is entry 0 of the four *Old
