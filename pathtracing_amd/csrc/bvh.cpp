@@ -11,7 +11,7 @@
 namespace ptrace {
 namespace {
 
-constexpr int kBins = 16;
+constexpr int kBins = 32;   // 16 / 32 / 64 / 128 bins: 16.2 / 14.9 / 15.2 / 15.5 node visits per ray on the 262 k-triangle bench scene, equal within 2 % on the 70 k one
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 struct Tmp {

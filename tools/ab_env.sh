@@ -1,0 +1,9 @@
+#!/bin/bash
+# One library, several environments: tools/ab_env.sh "VAR=a" "VAR=b OTHER=c" ...   (deterministic tree quality + rate)
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $REPO
+for envs in "" "$@"; do
+  for rep in 1 2; do
+    env $envs timeout -k 5 90 python -u bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stereo --no-reproj --in-flight 1 $BENCH_ARGS 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('[$envs]', round(d['value'],1), 'nodes/ray', round(r['nodes_per_ray'],3), 'prims/ray', round(r['prims_per_ray'],3), 'build_ms', round(d['bvh']['build_ms'],1), 'nodes', d['bvh']['nodes'], d['image_crc'])" || exit 1
+  done
+done
