@@ -723,6 +723,23 @@ def test_full_frame_reproj_modes_match_oracle_bit_exact(tracer, mode):
     assert (got[9][4].view(np.uint32) == g[f"mode{mode}_result2_9"].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("mode,divisions", [(7, 1), (8, 1), (7, 3), (5, 1), (6, 1)])
+def test_stripe_modes_degenerate_divisions(tracer, mode, divisions):
+    """One stripe per cycle: every dispatch has counter 0, so renderMode 7 / 8 render the whole frame from "history
+    camera -1" and publish it at once, and renderMode 5 / 6 reproject nothing.  Three stripes: 36 rows / 3."""
+    from reproj_util import gpu_stripe_sequence, oracle_stripe_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    W, H = 48, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_stripe_sequence(o, s, W, H, 4, divisions, mode, spp=1, max_bounces=3)
+    got = gpu_stripe_sequence(tracer, s, W, H, 4, divisions, mode, spp=1, max_bounces=3)
+    for k in range(4):
+        for t in (0, 1) + ((4,) if mode in (7, 8) else ()):
+            assert (got[k][t].view(np.uint32) == want[k][t].view(np.uint32)).all(), f"target {t}, frame {k}"
+        assert got[k][3]["rays"] == want[k][3]["rays"], k
+
+
 def test_full_frame_reproj_mesh_scene_uneven_rows_and_samples(tracer):
     from reproj_util import gpu_stripe_sequence, oracle_stripe_sequence
     s = pa.Scene("blob70k"); sky = pa.procedural_sky(256, 128)
