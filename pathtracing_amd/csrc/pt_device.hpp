@@ -93,7 +93,7 @@ constexpr int kBlock = 256;            // 4 waves
 constexpr int kWorkShards = 64;        // most counters a frame is split over: one hot counter serialises the pixel claims
                                        // of a 1-spp frame at the L2, many counters scatter the waves over the image
 constexpr int kWorkStride = 16;        // u32 words between counters: one cache line each
-constexpr int kStackLds = 16;          // traversal stack entries kept in LDS per lane
+constexpr int kStackLds = 12;          // traversal stack entries kept in LDS per lane
 constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 96 >= the deepest stack:
                                        // kMaxDepth (60) pushes for two-child nodes, 3 * ceil(60 / 2) for four-child nodes
 constexpr int kDoneNode = (int)0x80000000;   // traversal state "stack empty: ray finished"
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #undef ls3
 
 template <int WIDE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_kernel(const RenderArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void path_sched_kernel(const RenderArgs a)
 {
     path_sched_body<WIDE, false>(a);
 }
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 // The same kernel for scenes whose mesh objects carry materials (pt_set_mesh_materials); kept apart so that
 // the extra shading code cannot cost the default kernel registers.
 template <int WIDE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void path_sched_mat_kernel(const RenderArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void path_sched_mat_kernel(const RenderArgs a)
 {
     path_sched_body<WIDE, true>(a);
 }

@@ -89,7 +89,7 @@ struct pt_context {
     int refill_threshold = 32;
     int node_vote = 8;
     int vote_shade = 44, vote_node = 16;
-    int sched_blocks_per_cu = 0;
+    int sched_blocks_per_cu = 0, sched_ext_blocks_per_cu = 0;   // resident blocks per CU of path_sched_kernel / path_sched_mat_kernel
     int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
     int reuse_primary = 0;                 // option "reuse_primary_hit"
     int backend = 0;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
@@ -507,6 +507,8 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->shade_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_mat_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched_ext_blocks_per_cu = std::max(1, bpc);
     if (const char *env = std::getenv("PTRACE_BACKEND"))
         ctx->backend = std::strcmp(env, "mega") == 0 ? 0 : 1;
     if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
@@ -732,7 +734,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         a.shard_items = ((blocks + a.n_shards - 1) / a.n_shards) * 64u;
     }
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-    const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, ctx->sched_blocks_per_cu) : ctx->sched_blocks_per_cu;
+    const int fit = extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
+    const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, fit) : fit;
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * per_cu);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
