@@ -93,8 +93,9 @@ constexpr int kBlock = 256;            // 4 waves
 constexpr int kWorkShards = 64;        // most counters a frame is split over: one hot counter serialises the pixel claims
                                        // of a 1-spp frame at the L2, many counters scatter the waves over the image
 constexpr int kWorkStride = 16;        // u32 words between counters: one cache line each
-constexpr int kStackLds = 12;          // traversal stack entries kept in LDS per lane
-constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 96 >= the deepest stack:
+constexpr int kStackLds = 12;          // traversal stack entries kept in LDS per lane: with the path kernel's other LDS arrays that
+                                       // is 31 KB per block, so five blocks fit the 160 KB of a CU
+constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 92 >= the deepest stack:
                                        // kMaxDepth (60) pushes for two-child nodes, 3 * ceil(60 / 2) for four-child nodes
 constexpr int kDoneNode = (int)0x80000000;   // traversal state "stack empty: ray finished"
 
@@ -1052,6 +1053,9 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #undef ls2
 #undef ls3
 
+// Five waves per SIMD (96 VGPRs): the few values that do not fit are kernel constants spilled once at entry and read back
+// in the shade phase; the node and leaf loops hold no scratch access.  Measured against four waves (128 VGPRs, nothing
+// spilled): +2.5 % rays/s one dispatch at a time, +6 % with three in flight; six waves (80 VGPRs) lose.
 template <int WIDE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void path_sched_kernel(const RenderArgs a)
 {
