@@ -970,3 +970,49 @@ def test_group_reduce_adds_the_members_images_in_index_order(sky_small):
             grp.reduce(root=0)
     with pytest.raises(pa.PtraceError, match="ordinal"):
         pa.PathTracerGroup([0, 4096])
+
+
+def test_deep_traversal_stack_spills_to_the_overflow_buffer(tracer):
+    """16 384 large, nearly coincident triangles stacked 0.01 apart in depth: a ray through the stack enters every
+    child box of every node on its way down, so the traversal stack grows by three entries per level of the four-wide
+    tree (one per level of the binary tree) - far past the entries kept in LDS - before the first hit prunes anything.
+    Image, hit ids and ray queries must not notice where an entry is stored."""
+    n = 16384
+    rng = np.random.default_rng(11)
+    z = (np.arange(n) * 0.01).astype(np.float32)
+    jit = rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32)
+    v = np.zeros((n, 3, 3), np.float32)
+    base = np.array([[-40.0, -30.0], [0.0, 45.0], [40.0, -30.0]], np.float32)
+    for c in range(3):
+        v[:, c, 0] = base[c, 0] + jit[:, 0]; v[:, c, 1] = base[c, 1] + jit[:, 1]; v[:, c, 2] = z
+    idx = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    idx[1::2] = idx[1::2, ::-1]                                   # every other one faces away (culled, SH:206)
+    objs = np.zeros(1, dtype=np.dtype([("m", np.float32, 16), ("offset", np.int32), ("count", np.int32)]))
+    objs[0] = (np.eye(4, dtype=np.float32).reshape(16), 0, 3 * n)
+    spheres = np.zeros((0, 14), np.float32)
+    sky = pa.procedural_sky(64, 32)
+    verts = v.reshape(-1, 3); index = idx.reshape(-1)
+    tracer.set_spheres(spheres); tracer.set_meshes(objs, verts, index); tracer.set_sky(sky)
+    orc = po.Oracle(spheres, objs, verts, index, sky=sky, accel=True)
+    W, H = 64, 36
+    tracer.resize(W, H)
+    f = pa.Scene("fixture")
+    for eye, target in (((0.0, 2.0, -6.0), (0.0, 2.0, 0.0)), ((3.0, -1.0, n * 0.01 + 6.0), (0.0, 0.0, 0.0))):
+        p = pa.make_params(f, W, H, seed=0.375, spp=2, max_bounces=4, eye=eye, target=target)
+        tracer.stats(); tracer.render(p)
+        g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+        c, cid, cst = orc.render(p, W, H, threads=8)
+        assert (gid == cid).all()
+        _assert_same_image(g, c, f"stack of triangles seen from {eye}")
+        assert st["rays"] == cst["rays"]
+        assert (gid > 0).mean() > 0.5                             # the stack fills most of the view
+        # a camera ray descends ~7 levels pushing 3 siblings at each (21 entries) and pops every one of them again;
+        # the reflected rays leave the stack at once, which pulls the mean down
+        assert st["nodes_visited"] / st["rays"] > 8
+    # ray queries: the tree against the exhaustive loop on the device
+    od = np.zeros((2000, 6), np.float32)
+    od[:, :2] = rng.uniform(-20, 20, (2000, 2)); od[:, 2] = -5.0
+    d = rng.normal(0, 0.15, (2000, 3)); d[:, 2] = 1.0
+    od[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    ib, tb = tracer.trace_rays(od); ie, te = tracer.trace_rays(od, brute_force=True)
+    assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
