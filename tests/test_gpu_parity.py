@@ -1009,6 +1009,17 @@ def test_deep_traversal_stack_spills_to_the_overflow_buffer(tracer):
         # a camera ray descends ~7 levels pushing 3 siblings at each (21 entries) and pops every one of them again;
         # the reflected rays leave the stack at once, which pulls the mean down
         assert st["nodes_visited"] / st["rays"] > 8
+    # the one-pass primary kernel (_Depth dispatch) and the extended path kernel (a material on the mesh) share the stack code
+    pd = pa.make_params(f, W, H, depth=1, eye=(0.0, 2.0, -6.0), target=(0.0, 2.0, 0.0))
+    tracer.render(pd)
+    _assert_same_image(tracer.read_result(), orc.render(pd, W, H, threads=8)[0], "depth dispatch through the stack of triangles")
+    mats = pa.materials([((0.2, 0.3, 0.4), 0.6, (0.5, 0.5, 0.5), pa.PT_LOBE_GGX)])
+    tracer.set_mesh_materials(mats)
+    orc_m = po.Oracle(spheres, objs, verts, index, sky=sky, accel=True, materials=mats)
+    pm = pa.make_params(f, W, H, seed=0.625, spp=2, max_bounces=4, eye=(0.0, 2.0, -6.0), target=(0.0, 2.0, 0.0))
+    tracer.render(pm)
+    _assert_same_image(tracer.read_result(), orc_m.render(pm, W, H, threads=8)[0], "extended kernel through the stack of triangles")
+    tracer.set_mesh_materials(None)
     # ray queries: the tree against the exhaustive loop on the device
     od = np.zeros((2000, 6), np.float32)
     od[:, :2] = rng.uniform(-20, 20, (2000, 2)); od[:, 2] = -5.0
