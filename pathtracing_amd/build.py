@@ -41,7 +41,7 @@ def _run(cmd, cwd):
 
 def build_ptrace(force=False):
     out = os.path.join(CSRC, "libptrace.so")
-    srcs = [os.path.join(CSRC, f) for f in ("ptrace_api.hip", "bvh.cpp", "bvh.hpp", "pt_device.hpp", "pt_wavefront.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ptrace_api.hip", "bvh.cpp", "bvh.hpp", "pt_device.hpp", "pt_wavefront.hpp", "pt_screen.hpp", "pt_refit.hpp")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("ptrace.h", "ptrace_fmath.h")]
     if force or _newer(out, srcs):
         _run([HIPCC] + HIP_FLAGS + ["-o", out, "ptrace_api.hip", "bvh.cpp", "-lpthread"], CSRC)
@@ -60,6 +60,16 @@ def build_ptmaster(force=False):
     return out
 
 
+def build_demo(force=False):
+    """The compiled host (no Python): host/ptrace_demo."""
+    out = os.path.join(HOST, "ptrace_demo")
+    srcs = [os.path.join(HOST, f) for f in ("ptrace_demo.cpp", "ray_tracing_master.hpp", "scene.hpp", "libptmaster.so")]
+    if force or _newer(out, srcs):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", out, "ptrace_demo.cpp", "-L" + HOST, "-lptmaster", "-L" + CSRC, "-lptrace",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../csrc"], HOST)
+    return out
+
+
 def build_oracle(force=False):
     out = os.path.join(ORACLE, "_build", "libptoracle.so")
     if force:
@@ -69,7 +79,7 @@ def build_oracle(force=False):
 
 
 def build_all(force=False):
-    return [build_ptrace(force), build_ptmaster(force), build_oracle(force)]
+    return [build_ptrace(force), build_ptmaster(force), build_demo(force), build_oracle(force)]
 
 
 if __name__ == "__main__":

@@ -1095,13 +1095,13 @@ __global__ __launch_bounds__(kBlock) void trace_rays_brute_kernel(SceneDev sc, c
     if (i >= n) return;
     f3 o = pt_make3(od[i * 6 + 0], od[i * 6 + 1], od[i * 6 + 2]);
     f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);
-    float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
+    float t = PT_INF; int32_t id = -1;
     intersect_ground_plane(o, d, t, id);
     for (int k = 0; k < sc.n_prims; k++) {
         // a fresh (+inf, max id) candidate, so that only a strict improvement over `t` is accepted
         float tc = PT_INF; int32_t ic = 0x7fffffff; uint32_t rc = 0;
         intersect_prim(sc.prims, by_id[k], o, d, tc, ic, rc);
-        if (tc < t) { t = tc; id = ic; rec = rc; }
+        if (tc < t) { t = tc; id = ic; }
     }
     ids[i] = id; ts[i] = t;
 }

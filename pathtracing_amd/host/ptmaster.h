@@ -75,9 +75,9 @@ int ptm_master_load_scene(ptm_master *m, const ptm_scene *s, int sky_w, int sky_
 /* Inspector fields (RayTracingMaster.cs:73-91, 686, 991) */
 int ptm_master_configure(ptm_master *m, int width, int height, int samples_per_pixel, int max_bounces,
                          int depth, int accumulate, uint32_t sample_frames);
-/* RayTracingMaster.renderMode (RayTracingMaster.cs:977-991): 0 Denoise, 1 Default, 2 Reproj, 5 PartialFrameReproj, 6 PartialFrameReprojDepth. */
+/* RayTracingMaster.renderMode (RayTracingMaster.cs:977-991): any value of the RenderMode enum (0 .. 8, 10, 11, 12). */
 int ptm_master_set_render_mode(ptm_master *m, int render_mode);
-/* RayTracingMaster.divisions (RayTracingMaster.cs:701): stripes per frame cycle in renderMode 5 / 6. */
+/* RayTracingMaster.divisions (RayTracingMaster.cs:701): stripes per frame cycle in renderMode 5 .. 8. */
 int ptm_master_set_divisions(ptm_master *m, int divisions);
 /* eye_offset: signed offset along the camera's right axis (stereo: -sep/2 left, +sep/2 right). */
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov_y_deg, float eye_offset);

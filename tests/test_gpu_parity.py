@@ -1027,3 +1027,38 @@ def test_deep_traversal_stack_spills_to_the_overflow_buffer(tracer):
     od[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
     ib, tb = tracer.trace_rays(od); ie, te = tracer.trace_rays(od, brute_force=True)
     assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
+
+
+def test_compiled_host_renders_what_the_ctypes_harness_renders():
+    """host/ptrace_demo (C++ RayTracingMaster mirror + libptrace, no Python in the process) against the same mirror
+    driven through ctypes: same frames, same checksum."""
+    import ctypes as C
+    import json
+    import subprocess
+    from pathtracing_amd import _ffi
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pathtracing_amd", "host", "ptrace_demo")
+    assert os.path.exists(exe), "host/ptrace_demo is not built (python -m pathtracing_amd.build)"
+    W, H, frames = 96, 54, 3
+    out = subprocess.run([exe, "--scene", "fixture", "--size", f"{W}x{H}", "--spp", "2", "--bounces", "4", "--frames", str(frames)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["rays"] > frames * W * H * 2 and rep["mrays_per_s"] > 0
+    lib = _ffi.ptmaster()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        assert lib.ptm_master_load_scene(h, s.handle, 2048, 1024) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, W, H, 2, 4, 0, pa.PT_ACCUM_NONE, 10)
+        lib.ptm_master_set_camera(h, (C.c_float * 3)(*s.eye), (C.c_float * 3)(*s.target), C.c_float(s.fov), C.c_float(0.0))
+        for _ in range(frames + 1):
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+        img = np.empty((H, W, 4), np.float32)
+        assert _ffi.ptrace().pt_read_result(lib.ptm_master_context(h), img.ctypes.data) == 0
+    finally:
+        lib.ptm_master_destroy(h)
+    assert int(np.bitwise_xor.reduce(img.view(np.uint32).reshape(-1))) == rep["image_crc"]
+    assert np.allclose(img[..., :3].reshape(-1, 3).mean(0), rep["image_mean_rgb"], rtol=1e-4)
+    bad = subprocess.run([exe, "--scene", "nowhere"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "unknown scene" in bad.stderr
