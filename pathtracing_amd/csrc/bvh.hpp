@@ -28,6 +28,11 @@ struct alignas(64) BvhNode {
     float rhi[3]; int32_t pad1;
 };
 
+// A primitive with a NaN or infinite coordinate (or one beyond this magnitude) gets the box [-kHugeCoord, kHugeCoord] on that
+// axis: finite, so that centroids, extents and the quantised node grids stay well defined, and so large that every ray of a
+// real scene passes through it.  With the traversal's reciprocal direction clamped at 1e18 the products stay below 3.4e38.
+constexpr float kHugeCoord = 1e18f;
+
 constexpr int kMaxLeafPrims = 8;   // what the 3-bit count field can hold
 constexpr int kMaxDepth = 60;      // traversal stack capacity bounds the depth
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
         // a NaN coordinate must widen the box, not vanish in fmin/fmax
         if (!(v0.x == v0.x && v1.x == v1.x && v2.x == v2.x)) { lo[0] = -PT_INF; hi[0] = PT_INF; }
         if (!(v0.y == v0.y && v1.y == v1.y && v2.y == v2.y)) { lo[1] = -PT_INF; hi[1] = PT_INF; }
-        if (!(v0.z == v0.z && v1.z == v1.z && v2.z == v2.z)) { lo[2] = -PT_INF; hi[2] = PT_INF; }
+        if (!(v0.z == v0.z && v1.z == v1.z && v2.z == v2.z)) { lo[2] = -PT_INF; hi[2] = PT_INF; }   // made finite below
     } else {
         const float4 c = a.prims[(size_t)slot * 3 + 0];
         const float r = fabsf(a.prims[(size_t)slot * 3 + 1].x);
@@ -66,10 +66,10 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float l = lo[k], h = hi[k];
-        const bool finite = fabsf(l) < PT_INF && fabsf(h) < PT_INF;
+        const bool usable = fabsf(l) < kHugeCoord && fabsf(h) < kHugeCoord;   // false for NaN too: the same rule as the host build
         const float rel = 4e-7f * fmaxf(fabsf(l), fabsf(h));
-        a.prim_box[(size_t)slot * 6 + k] = finite ? l - a.pad - rel : -PT_INF;
-        a.prim_box[(size_t)slot * 6 + 3 + k] = finite ? h + a.pad + rel : PT_INF;
+        a.prim_box[(size_t)slot * 6 + k] = usable ? l - a.pad - rel : -kHugeCoord;
+        a.prim_box[(size_t)slot * 6 + 3 + k] = usable ? h + a.pad + rel : kHugeCoord;
     }
 }
 

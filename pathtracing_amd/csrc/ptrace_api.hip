@@ -215,8 +215,8 @@ int rebuild_scene(pt_context *ctx)
     }
     for (size_t i = 0; i < nP; i++)
         for (int k = 0; k < 3; k++) {
-            if (std::isfinite(boxes[i].lo[k])) slo[k] = std::min(slo[k], boxes[i].lo[k]);
-            if (std::isfinite(boxes[i].hi[k])) shi[k] = std::max(shi[k], boxes[i].hi[k]);
+            if (std::fabs(boxes[i].lo[k]) < kHugeCoord) slo[k] = std::min(slo[k], boxes[i].lo[k]);
+            if (std::fabs(boxes[i].hi[k]) < kHugeCoord) shi[k] = std::max(shi[k], boxes[i].hi[k]);
         }
     // Pad every box: the intersection tests accept hits a few ulps outside the exact primitive.
     float diag = 0.0f;
@@ -228,7 +228,7 @@ int rebuild_scene(pt_context *ctx)
         for (int k = 0; k < 3; k++) {
             float l = boxes[i].lo[k], h = boxes[i].hi[k];
             float rel = 4e-7f * std::max(std::fabs(l), std::fabs(h));
-            if (!std::isfinite(l) || !std::isfinite(h)) { boxes[i].lo[k] = -INFINITY; boxes[i].hi[k] = INFINITY; continue; }
+            if (!(std::fabs(l) < kHugeCoord) || !(std::fabs(h) < kHugeCoord)) { boxes[i].lo[k] = -kHugeCoord; boxes[i].hi[k] = kHugeCoord; continue; }
             boxes[i].lo[k] = l - pad - rel; boxes[i].hi[k] = h + pad + rel;
         }
 

@@ -1062,3 +1062,35 @@ def test_compiled_host_renders_what_the_ctypes_harness_renders():
     assert np.allclose(img[..., :3].reshape(-1, 3).mean(0), rep["image_mean_rgb"], rtol=1e-4)
     bad = subprocess.run([exe, "--scene", "nowhere"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "unknown scene" in bad.stderr
+
+
+def test_non_finite_geometry_does_not_hide_the_rest_of_the_scene(tracer, sky_small):
+    """Vertices and spheres holding NaN or infinity: the shader's tests on them come out false (every comparison with
+    NaN does), so they are never hit - and everything else must render as if they were not there, after a build and
+    after a refit alike."""
+    s = pa.Scene("fixture")
+    verts = np.array(s.vertices, np.float32).reshape(-1, 3).copy()
+    verts[5, 0] = np.nan; verts[40, 1] = np.inf; verts[77] = (-np.inf, np.nan, 3.0); verts[120, 2] = -np.inf
+    spheres = np.array(s.spheres, np.float32).reshape(-1, 14).copy()
+    spheres[2, 0] = np.nan                        # position.x
+    spheres[6, 3] = np.inf                        # radius
+    spheres[9, 1] = -np.inf
+    tracer.set_spheres(spheres); tracer.set_meshes(s.objects, verts, s.indices); tracer.set_sky(sky_small)
+    orc = po.Oracle(spheres, s.objects, verts, s.indices, sky=sky_small, accel=False)
+    W, H = 64, 36
+    tracer.resize(W, H)
+    p = pa.make_params(s, W, H, seed=0.5, spp=2, max_bounces=4)
+    tracer.render(p)
+    c, cid, _ = orc.render(p, W, H, threads=8)
+    assert (cid > 0).sum() > 300                                  # plenty of ordinary geometry left to see
+    assert (tracer.read_hit_ids() == cid).all()
+    _assert_same_image(tracer.read_result(), c, "scene with non-finite vertices and spheres")
+    objs = np.array(s.objects).copy()
+    objs["m"][0][12] += 0.75                                      # translate in x: a refit on the device
+    tracer.update_transforms(objs)
+    orc2 = po.Oracle(spheres, objs, verts, s.indices, sky=sky_small, accel=False)
+    tracer.render(p)
+    c2, cid2, _ = orc2.render(p, W, H, threads=8)
+    assert (tracer.read_hit_ids() == cid2).all()
+    _assert_same_image(tracer.read_result(), c2, "the same after a refit")
+    assert not (cid2 == cid).all()

@@ -1,0 +1,106 @@
+// Host-only check of the BVH builder (csrc/bvh.cpp), meant to be built with -fsanitize=address,undefined:
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -I include -I pathtracing_amd/csrc -I pathtracing_amd/host \
+//       tools/bvh_check.cpp pathtracing_amd/csrc/bvh.cpp pathtracing_amd/host/scene_gen.cpp -lpthread -o /tmp/bvh_check && /tmp/bvh_check
+// For named scenes and for degenerate inputs it verifies, on both device layouts, that every primitive sits in exactly one
+// leaf, that every (dequantised) child box contains the boxes below it, and that the depth stays within kMaxDepth.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "bvh.hpp"
+#include "scene.hpp"
+
+using ptrace::Aabb;
+
+static bool contains(const float *lo, const float *hi, const Aabb &b)
+{
+    for (int k = 0; k < 3; k++)
+        if (std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && !(lo[k] <= b.lo[k] && hi[k] >= b.hi[k])) return false;
+    return true;
+}
+
+static int check(const char *what, const std::vector<Aabb> &boxes, int leaf)
+{
+    ptrace::BvhResult r = ptrace::build_bvh(boxes, leaf, 0, 1.0f);
+    const size_t n = boxes.size();
+    if (n == 0) { std::printf("%-28s empty: %zu nodes\n", what, r.nodes.size()); return r.nodes.empty() && r.nodes4.empty() ? 0 : 1; }
+    int bad = 0;
+    std::vector<int> seen(n, 0);
+    for (uint32_t id : r.order) { if (id >= n) bad++; else seen[id]++; }
+    for (int c : seen) if (c != 1) bad++;
+    // four-wide layout: walk it, dequantise, test containment of every primitive of a leaf and count leaf coverage
+    std::vector<int> cover(n, 0);
+    struct It { int32_t node; int depth; };
+    std::vector<It> st{{0, 1}};
+    int depth = 0;
+    while (!st.empty()) {
+        It it = st.back(); st.pop_back();
+        depth = std::max(depth, it.depth);
+        const ptrace::Bvh4Node &nd = r.nodes4[(size_t)it.node];
+        const float cell[3] = {std::ldexp(1.0f, nd.ex - 127), std::ldexp(1.0f, nd.ey - 127), std::ldexp(1.0f, nd.ez - 127)};
+        for (int k = 0; k < 4; k++) {
+            if (!((nd.valid >> k) & 1)) continue;
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) { lo[a] = nd.org[a] + nd.qlo[a][k] * cell[a]; hi[a] = nd.org[a] + nd.qhi[a][k] * cell[a]; }
+            if (nd.child[k] >= 0) { st.push_back({nd.child[k], it.depth + 1}); continue; }
+            uint32_t enc = (uint32_t)~nd.child[k], first = enc >> 3, count = (enc & 7u) + 1u;
+            for (uint32_t s = first; s < first + count; s++) {
+                if (s >= n) { bad++; continue; }
+                cover[r.order[s]]++;
+                if (!contains(lo, hi, boxes[r.order[s]])) bad++;
+            }
+        }
+    }
+    for (int c : cover) if (c != 1) bad++;
+    if (depth > ptrace::kMaxDepth || r.depth > ptrace::kMaxDepth) bad++;
+    std::printf("%-28s %8zu prims: %7zu nodes, %7zu wide nodes, depth %2d / %2d, %s\n", what, n, r.nodes.size(), r.nodes4.size(), r.depth,
+                depth, bad ? "INVALID" : "ok");
+    return bad;
+}
+
+int main()
+{
+    int bad = 0;
+    for (const char *name : {"fixture", "blob70k", "hall260k"}) {
+        std::unique_ptr<ptm::Scene> s(ptm::Scene::create(name));
+        std::vector<Aabb> boxes;
+        for (const PtSphere &sp : s->spheres) {
+            Aabb b;
+            for (int k = 0; k < 3; k++) { b.lo[k] = sp.position[k] - sp.radius; b.hi[k] = sp.position[k] + sp.radius; }
+            boxes.push_back(b);
+        }
+        for (size_t i = 0; i + 2 < s->indices.size(); i += 3) {
+            Aabb b;
+            for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+            for (int c = 0; c < 3; c++)
+                for (int k = 0; k < 3; k++) {
+                    float v = s->vertices[(size_t)s->indices[i + c] * 3 + k];
+                    b.lo[k] = std::fmin(b.lo[k], v); b.hi[k] = std::fmax(b.hi[k], v);
+                }
+            boxes.push_back(b);
+        }
+        for (int leaf : {1, 2, 4}) bad += check((std::string(name) + " leaf " + std::to_string(leaf)).c_str(), boxes, leaf);
+    }
+    std::mt19937 rng(5);
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    auto point_box = [](float x, float y, float z, float h) { Aabb b = {{x - h, y - h, z - h}, {x + h, y + h, z + h}}; return b; };
+    bad += check("no primitives", {}, 2);
+    bad += check("one primitive", {point_box(0, 0, 0, 1)}, 2);
+    bad += check("two identical", {point_box(1, 2, 3, 0.5f), point_box(1, 2, 3, 0.5f)}, 2);
+    { std::vector<Aabb> b(5000, point_box(0.25f, -3, 7, 0.125f)); bad += check("5000 identical boxes", b, 2); }
+    { std::vector<Aabb> b; for (int i = 0; i < 4000; i++) b.push_back(point_box((float)i * 1e-3f, 0, 0, 0.0f)); bad += check("4000 points on a line", b, 2); }
+    { std::vector<Aabb> b; for (int i = 0; i < 3000; i++) b.push_back(point_box(u(rng), u(rng), u(rng), 0.01f));
+      // what the library hands the builder for a primitive with a NaN or infinite coordinate
+      b[7].lo[1] = -ptrace::kHugeCoord; b[7].hi[1] = ptrace::kHugeCoord;
+      for (int k = 0; k < 3; k++) { b[99].lo[k] = -ptrace::kHugeCoord; b[99].hi[k] = ptrace::kHugeCoord; }
+      bad += check("random + two huge boxes", b, 2); }
+    { std::vector<Aabb> b; for (int i = 0; i < 20000; i++) { float s = std::ldexp(1.0f, -(i % 40)); b.push_back(point_box(s, s, s, s * 0.25f)); }
+      bad += check("geometric sizes (deep tree)", b, 1); }
+    { std::vector<Aabb> b; for (int i = 0; i < 2000; i++) b.push_back(point_box(u(rng) * 1e30f, u(rng) * 1e-30f, u(rng), 1e20f)); bad += check("huge and tiny extents", b, 2); }
+    std::printf(bad ? "bvh_check FAILED (%d)\n" : "bvh_check ok\n", bad);
+    return bad != 0;
+}
