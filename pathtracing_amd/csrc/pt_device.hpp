@@ -28,6 +28,20 @@ struct SceneDev {
     int32_t n_nodes, n_prims, n_spheres;
 };
 
+// How far outside a triangle the Moeller-Trumbore arithmetic (SH:192-230) can still report a hit.  Its barycentric
+// coordinates come out of cross and dot products of the edges with the ray's offset from vertex 0, so their rounding error
+// grows with the edge length L, with the offset's length (at most `reach`) and with the triangle's thinness L / altitude
+// = L * L / |e1 x e2|; in world units: about 8 eps * (L * L / |e1 x e2|) * max(L, reach).  Ordinary meshes stay below the
+// general padding; a sliver that runs out to 1e6 gets a box as wide as its bogus hits reach.  Infinite for zero area.
+__host__ __device__ inline float triangle_fuzz(pt_f3 e1, pt_f3 e2, float reach)
+{
+    const pt_f3 e3 = pt_sub3(e2, e1);
+    const float l2 = fmaxf(pt_dot3(e1, e1), fmaxf(pt_dot3(e2, e2), pt_dot3(e3, e3)));
+    const pt_f3 n = pt_cross3(e1, e2);
+    const float area2 = sqrtf(pt_dot3(n, n));
+    return 8.0f * 5.9604645e-8f * (l2 / area2) * fmaxf(sqrtf(l2), reach);
+}
+
 // Primitive record (48 B): a = (v0.xyz, bits(id)), b = (e1.xyz, bits(kind)), c = (e2.xyz, bits(mesh object index))
 // with e1 = v1 - v0, e2 = v2 - v0 in world space (kind 0), or for a sphere
 // a = (centre.xyz, bits(id)), b = (radius, 0, 0, bits(1)).

@@ -25,6 +25,8 @@ struct RefitArgs {
     float *node_box;          // 6 floats per node: exact union of its children's boxes
     const int32_t *level_nodes;   // node indices, deepest level first
     float pad;                // absolute padding of primitive boxes (from the last full build)
+    float reach;              // largest distance between a ray's origin and a primitive the boxes are padded for
+    float sphere_slack2;      // a sphere's box has radius sqrt(r * r + sphere_slack2): the reach of IntersectSphere's rounding
     int32_t n_prims;
 };
 
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
     if (slot >= a.n_prims) return;
     const int4 src = a.slot_src[slot];
     float lo[3], hi[3];
+    float own = 0.0f;         // padding this primitive's own intersection arithmetic needs (triangle_fuzz)
     if (src.x >= 0) {
         const float *m = a.matrices + 16 * (size_t)src.x;
         float mm[16];
@@ -47,6 +50,8 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
         const f3 v1 = pt_mul_point(mm, pt_make3(pb[0], pb[1], pb[2]));
         const f3 v2 = pt_mul_point(mm, pt_make3(pc[0], pc[1], pc[2]));
         const f3 e1 = pt_sub3(v1, v0), e2 = pt_sub3(v2, v0);
+        own = triangle_fuzz(e1, e2, a.reach);
+        if (!(own < kHugeCoord)) own = kHugeCoord;
         const float idf = a.prims[(size_t)slot * 3].w;
         a.prims[(size_t)slot * 3 + 0] = make_float4(v0.x, v0.y, v0.z, idf);
         a.prims[(size_t)slot * 3 + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
@@ -60,16 +65,18 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
         if (!(v0.z == v0.z && v1.z == v1.z && v2.z == v2.z)) { lo[2] = -PT_INF; hi[2] = PT_INF; }   // made finite below
     } else {
         const float4 c = a.prims[(size_t)slot * 3 + 0];
-        const float r = fabsf(a.prims[(size_t)slot * 3 + 1].x);
+        const float r0 = a.prims[(size_t)slot * 3 + 1].x;
+        const float r = sqrtf(r0 * r0 + a.sphere_slack2);
         lo[0] = c.x - r; hi[0] = c.x + r; lo[1] = c.y - r; hi[1] = c.y + r; lo[2] = c.z - r; hi[2] = c.z + r;
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float l = lo[k], h = hi[k];
-        const bool usable = fabsf(l) < kHugeCoord && fabsf(h) < kHugeCoord;   // false for NaN too: the same rule as the host build
+        const float p = fmaxf(a.pad, own);
+        const bool usable = fabsf(l) + p < kHugeCoord && fabsf(h) + p < kHugeCoord;   // false for NaN too: the same rule as the host build
         const float rel = 4e-7f * fmaxf(fabsf(l), fabsf(h));
-        a.prim_box[(size_t)slot * 6 + k] = usable ? l - a.pad - rel : -kHugeCoord;
-        a.prim_box[(size_t)slot * 6 + 3 + k] = usable ? h + a.pad + rel : kHugeCoord;
+        a.prim_box[(size_t)slot * 6 + k] = usable ? l - p - rel : -kHugeCoord;
+        a.prim_box[(size_t)slot * 6 + 3 + k] = usable ? h + p + rel : kHugeCoord;
     }
 }
 

@@ -52,7 +52,13 @@ struct pt_context {
     float *d_vertices = nullptr, *d_matrices = nullptr, *d_prim_box = nullptr, *d_node_box = nullptr;
     int32_t *d_level_nodes = nullptr;
     std::vector<int> level_first;                  // level_first[l] .. level_first[l+1]: nodes of level l, deepest level first
-    float box_pad = 0.0f;
+    float box_pad = 0.0f, sphere_slack2 = 0.0f;    // what the last full build padded boxes with
+    // Sphere boxes are inflated for rays whose origin lies within `sphere_reach` of the sphere (see rebuild_scene); a camera
+    // farther away than that asks for a rebuild with a larger reach (ensure_scene).
+    float sphere_reach = 0.0f, sphere_reach_request = 0.0f;
+    float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};   // finite bounds of the scene: last build, or estimate after a refit
+    float spheres_lo[3] = {0, 0, 0}, spheres_hi[3] = {0, 0, 0};
+    std::vector<Aabb> object_box;                  // object-space bounds of every mesh object (for that estimate)
     hipEvent_t ev_refit = nullptr;
     bool refit_in_flight = false;
     bool bvh2_stale = false;                       // a refit updated only the four-wide tree
@@ -180,14 +186,19 @@ int rebuild_scene(pt_context *ctx)
     size_t nt = 0;
     for (const PtMeshObject &mo : ctx->objects) nt += (size_t)std::max(0, mo.indices_count) / 3;
     tris.reserve(nt); tri_object.reserve(nt);
+    ctx->object_box.assign(ctx->objects.size(), Aabb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}});
     for (size_t oi = 0; oi < ctx->objects.size(); oi++) {
         const PtMeshObject &mo = ctx->objects[oi];
         const int32_t end = mo.indices_offset + mo.indices_count;
+        Aabb &ob = ctx->object_box[oi];
         for (int32_t i = mo.indices_offset; i + 2 < end; i += 3) {
             tri_object.push_back((int32_t)oi);
             const float *a = &ctx->vertices[3 * (size_t)ctx->indices[i]];
             const float *b = &ctx->vertices[3 * (size_t)ctx->indices[i + 1]];
             const float *c = &ctx->vertices[3 * (size_t)ctx->indices[i + 2]];
+            for (const float *v : {a, b, c})
+                for (int k = 0; k < 3; k++)
+                    if (std::fabs(v[k]) < kHugeCoord) { ob.lo[k] = std::min(ob.lo[k], v[k]); ob.hi[k] = std::max(ob.hi[k], v[k]); }
             Tri t;
             t.v0 = pt_mul_point(mo.local_to_world, pt_make3(a[0], a[1], a[2]));
             t.v1 = pt_mul_point(mo.local_to_world, pt_make3(b[0], b[1], b[2]));
@@ -224,13 +235,44 @@ int rebuild_scene(pt_context *ctx)
                              (shi[2] - slo[2]) * (shi[2] - slo[2]));
     if (!std::isfinite(diag)) diag = 0.0f;
     const float pad = 1e-5f * diag + 1e-6f;
-    for (size_t i = 0; i < nP; i++)
+    // IntersectSphere (SH:170-190) decides hit or miss by the sign of p1*p1 - dot(d,d) + r*r with d = origin - centre:
+    // a difference of squares of the ray's distance to the sphere, so rounding lets it accept rays that pass up to
+    // sqrt(r*r + k*eps*|d|^2) from the centre (for r = 0 that is |d| * 7e-4, far more than `pad`).  The box must hold
+    // that fuzzy sphere, or the tree would cull hits the exhaustive loop finds: radius sqrt(r*r + slack2) with k = 8 and
+    // |d| <= `reach`.
+    // rays that start inside the scene are at most one diagonal away; cameras farther out raise the request (ensure_scene)
+    const float reach = std::max(2.0f * diag, ctx->sphere_reach_request);
+    const float sphere_slack2 = 8.0f * 5.9604645e-8f * reach * reach;
+    ctx->sphere_reach = reach;
+    for (int k = 0; k < 3; k++) {
+        ctx->scene_lo[k] = slo[k] <= shi[k] ? slo[k] : 0.0f; ctx->scene_hi[k] = slo[k] <= shi[k] ? shi[k] : 0.0f;
+        ctx->spheres_lo[k] = INFINITY; ctx->spheres_hi[k] = -INFINITY;
+    }
+    for (int i = 0; i < nS; i++)
+        for (int k = 0; k < 3; k++) {
+            if (std::fabs(boxes[i].lo[k]) < kHugeCoord) ctx->spheres_lo[k] = std::min(ctx->spheres_lo[k], boxes[i].lo[k]);
+            if (std::fabs(boxes[i].hi[k]) < kHugeCoord) ctx->spheres_hi[k] = std::max(ctx->spheres_hi[k], boxes[i].hi[k]);
+        }
+    for (int i = 0; i < nS; i++) {
+        const PtSphere &s = ctx->spheres[i];
+        const float r = std::sqrt(s.radius * s.radius + sphere_slack2);
+        for (int k = 0; k < 3; k++) { boxes[i].lo[k] = s.position[k] - r; boxes[i].hi[k] = s.position[k] + r; }
+    }
+    for (size_t i = 0; i < nP; i++) {
+        float own = 0.0f;      // what this primitive's own intersection arithmetic needs beyond the general padding
+        if (i >= (size_t)nS) {
+            const Tri &t = tris[i - nS];
+            own = triangle_fuzz(pt_sub3(t.v1, t.v0), pt_sub3(t.v2, t.v0), reach);
+            if (!(own < kHugeCoord)) own = kHugeCoord;           // zero area, NaN: the huge box below
+        }
         for (int k = 0; k < 3; k++) {
             float l = boxes[i].lo[k], h = boxes[i].hi[k];
             float rel = 4e-7f * std::max(std::fabs(l), std::fabs(h));
-            if (!(std::fabs(l) < kHugeCoord) || !(std::fabs(h) < kHugeCoord)) { boxes[i].lo[k] = -kHugeCoord; boxes[i].hi[k] = kHugeCoord; continue; }
-            boxes[i].lo[k] = l - pad - rel; boxes[i].hi[k] = h + pad + rel;
+            const float p = std::max(pad, own);
+            if (!(std::fabs(l) + p < kHugeCoord) || !(std::fabs(h) + p < kHugeCoord)) { boxes[i].lo[k] = -kHugeCoord; boxes[i].hi[k] = kHugeCoord; continue; }
+            boxes[i].lo[k] = l - p - rel; boxes[i].hi[k] = h + p + rel;
         }
+    }
 
     int leaf_size = 2;   // small leaves keep the lanes of a leaf phase in step; measured best of 1..4
     if (const char *env = std::getenv("PTRACE_LEAF")) leaf_size = std::max(1, std::min(4, std::atoi(env)));
@@ -315,7 +357,7 @@ int rebuild_scene(pt_context *ctx)
         free_dev(ctx->d_prim_box); free_dev(ctx->d_node_box);
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_prim_box, nP * 6 * sizeof(float)));
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_node_box, nN * 6 * sizeof(float)));
-        ctx->box_pad = pad;
+        ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
         ctx->refit_ready = !ctx->objects.empty();
     }
     if ((rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;
@@ -338,6 +380,35 @@ int rebuild_scene(pt_context *ctx)
                      std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_built).count());
     ctx->scene_dirty = false;
     ctx->bvh2_stale = false;
+    return PT_OK;
+}
+
+// The scene as the next launch needs it: rebuilt if something changed, and rebuilt once more with a larger reach if a ray
+// origin (a camera; `n` points, `stride` floats apart) lies farther from the scene than the sphere boxes were inflated for.
+int rebuild_scene(pt_context *ctx);
+int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
+{
+    if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
+    for (int pass = 0; pass < 2; pass++) {
+        if (ctx->scene_dirty) {
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            int rc = rebuild_scene(ctx);
+            if (rc) return rc;
+        }
+        if (ctx->spheres.empty()) break;
+        float c[3], half = 0.0f, need = 0.0f;
+        for (int k = 0; k < 3; k++) { c[k] = 0.5f * (ctx->scene_lo[k] + ctx->scene_hi[k]); const float e = ctx->scene_hi[k] - ctx->scene_lo[k]; half += e * e; }
+        half = 0.5f * std::sqrt(half);
+        for (int i = 0; i < n; i++) {
+            const float *o = origins + (size_t)i * stride;
+            const float d = std::sqrt((o[0] - c[0]) * (o[0] - c[0]) + (o[1] - c[1]) * (o[1] - c[1]) + (o[2] - c[2]) * (o[2] - c[2])) + half;
+            if (std::isfinite(d)) need = std::max(need, d);
+        }
+        need = std::max(need, 2.0f * half);          // rays that start inside the (possibly refitted) scene
+        if (!(need > ctx->sphere_reach)) break;
+        ctx->sphere_reach_request = 2.0f * need;
+        ctx->scene_dirty = true;
+    }
     return PT_OK;
 }
 
@@ -632,7 +703,7 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     RefitArgs ra;
     ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
     ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
-    ra.pad = ctx->box_pad; ra.n_prims = ctx->n_prims;
+    ra.pad = ctx->box_pad; ra.sphere_slack2 = ctx->sphere_slack2; ra.reach = ctx->sphere_reach; ra.n_prims = ctx->n_prims;
     hipLaunchKernelGGL(refit_prims_kernel, dim3((ctx->n_prims + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra);
     for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
         const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
@@ -643,6 +714,21 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     PT_HIP(ctx, hipEventRecord(ctx->ev_refit, ctx->stream));
     ctx->refit_in_flight = true;
     ctx->bvh2_stale = true;
+    // scene bounds after the move, from the objects' object-space boxes (an over-estimate is fine: it feeds ensure_scene)
+    for (int k = 0; k < 3; k++) { ctx->scene_lo[k] = ctx->spheres_lo[k]; ctx->scene_hi[k] = ctx->spheres_hi[k]; }
+    for (int o = 0; o < n_objects && o < (int)ctx->object_box.size(); o++) {
+        const Aabb &ob = ctx->object_box[(size_t)o];
+        if (!(ob.lo[0] <= ob.hi[0])) continue;
+        for (int corner = 0; corner < 8; corner++) {
+            const pt_f3 w = pt_mul_point(objects[o].local_to_world, pt_make3((corner & 1) ? ob.hi[0] : ob.lo[0], (corner & 2) ? ob.hi[1] : ob.lo[1],
+                                                                              (corner & 4) ? ob.hi[2] : ob.lo[2]));
+            const float wc[3] = {w.x, w.y, w.z};
+            for (int k = 0; k < 3; k++)
+                if (std::fabs(wc[k]) < kHugeCoord) { ctx->scene_lo[k] = std::min(ctx->scene_lo[k], wc[k]); ctx->scene_hi[k] = std::max(ctx->scene_hi[k], wc[k]); }
+        }
+    }
+    for (int k = 0; k < 3; k++)
+        if (!(ctx->scene_lo[k] <= ctx->scene_hi[k])) ctx->scene_lo[k] = ctx->scene_hi[k] = 0.0f;
     ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
 }
@@ -808,10 +894,15 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         return fail(ctx, PT_ERR_INVALID, "pt_render: renderMode 5..8 need 1 <= divisions <= 100 and 0 <= counter < divisions");
     DeviceGuard g(ctx->device);
     int rc;
-    if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
-    if (ctx->scene_dirty) {
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if ((rc = rebuild_scene(ctx))) return rc;
+    {
+        // ray origins of this dispatch: the camera, and in renderMode 7 / 8 the history camera the stripe is traced from
+        float cams[6] = {p->camera_to_world[12], p->camera_to_world[13], p->camera_to_world[14], 0, 0, 0};
+        int n_cams = 1;
+        if (full_reproj && (p->counter - 1) % p->divisions >= 0) {
+            const float *h = ctx->camera_history[(size_t)((p->counter - 1) % p->divisions)].camera_to_world;
+            cams[3] = h[12]; cams[4] = h[13]; cams[5] = h[14]; n_cams = 2;
+        }
+        if ((rc = ensure_scene(ctx, cams, n_cams, 3))) return rc;
     }
     const size_t pitch = (size_t)ctx->W * sizeof(float4);
     if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10) {
@@ -1094,8 +1185,7 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     DeviceGuard g(ctx->device);
     int rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
-    if (ctx->scene_dirty && (rc = rebuild_scene(ctx))) return rc;
+    if ((rc = ensure_scene(ctx, origins_dirs, n_rays, 6))) return rc;
     float *d_od = nullptr, *d_t = nullptr; int32_t *d_id = nullptr;
     auto cleanup = [&] { free_dev(d_od); free_dev(d_t); free_dev(d_id); };
     hipError_t e;

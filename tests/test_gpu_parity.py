@@ -1094,3 +1094,38 @@ def test_non_finite_geometry_does_not_hide_the_rest_of_the_scene(tracer, sky_sma
     assert (tracer.read_hit_ids() == cid2).all()
     _assert_same_image(tracer.read_result(), c2, "the same after a refit")
     assert not (cid2 == cid).all()
+
+
+def test_tree_keeps_the_hits_that_only_rounding_produces(tracer, sky_small):
+    """The shader's sphere test accepts rays that pass within |d| * ~7e-4 of a zero-radius sphere's centre (a difference
+    of squares of the distance), and its triangle test reports hits well outside a sliver triangle that runs out to 1e6.
+    Such hits are artefacts, but the exhaustive loop finds them, so the tree must too: primitive boxes are padded by the
+    reach of each test's rounding (found by tools/soak_geometry.py)."""
+    rng = np.random.default_rng(21)
+    spheres = np.zeros((6, 14), np.float32)
+    spheres[:, 0:3] = rng.uniform(-3, 3, (6, 3)); spheres[:, 1] += 4.0
+    spheres[:, 3] = [0.0, 0.0, 0.0, 1e-3, 1e-2, 0.5]
+    spheres[:, 11:14] = 3.0
+    v = np.array([[-0.75, 1, 2.25], [2, 1, 1], [2, 2, 0], [-2, 3, -2], [1e6, 4, 1e6], [0, 1e-6, -1], [3, -1, 3], [-1.75, -1, 3],
+                  [2.25, -1, -2], [0, 4, 3]], np.float32)
+    idx = np.array([[4, 6, 2], [2, 6, 4], [3, 4, 2], [4, 8, 1], [6, 4, 9], [4, 2, 0], [1, 3, 2], [5, 0, 2]], np.int32).reshape(-1)
+    objs = np.zeros(1, dtype=np.dtype([("m", np.float32, 16), ("offset", np.int32), ("count", np.int32)]))
+    objs[0] = (np.eye(4, dtype=np.float32).reshape(16), 0, len(idx))
+    tracer.set_spheres(spheres); tracer.set_meshes(objs, v, idx); tracer.set_sky(sky_small)
+    n = 40000
+    od = np.zeros((n, 6), np.float32)
+    od[:, :3] = rng.uniform(-25, 25, (n, 3)); od[:, 1] = np.abs(od[:, 1]) + 0.01
+    aim = spheres[rng.integers(0, 6, n), 0:3] + (rng.random((n, 1)) < 0.3) * rng.normal(0, 2e-3, (n, 3))   # mostly dead centre
+    d = aim - od[:, :3]
+    d[n // 2:] = rng.normal(0, 1, (n - n // 2, 3))                # the other half: anywhere, for the sliver triangles
+    od[:, 3:] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ib, tb = tracer.trace_rays(od); ie, te = tracer.trace_rays(od, brute_force=True)
+    assert (ib == ie).all(), f"{int((ib != ie).sum())} of {n} rays differ"
+    assert (tb.view(np.uint32) == te.view(np.uint32)).all()
+    zero_radius_hits = int(np.isin(ie[: n // 2], [1, 2, 3]).sum())
+    assert zero_radius_hits > 50, zero_radius_hits               # the artefact exists: a point gets hit
+    # a camera very far away asks for wider sphere boxes (a rebuild) instead of losing such hits
+    far = od[: n // 2].copy()
+    far[:, :3] = aim[: n // 2] - od[: n // 2, 3:] * 5000.0
+    ib, tb = tracer.trace_rays(far); ie, te = tracer.trace_rays(far, brute_force=True)
+    assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
