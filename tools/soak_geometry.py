@@ -16,7 +16,7 @@ from oracle import pt_oracle as po  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-sky = pa.procedural_sky(64, 32)
+skies = [pa.procedural_sky(64, 32), pa.procedural_sky(1, 1), pa.procedural_sky(7, 3), None]
 ref = pa.Scene("fixture")
 OBJ = ref.objects.dtype
 t = pa.PathTracer(0)
@@ -63,11 +63,24 @@ W, H = 24, 16
 while time.time() - t0 < budget:
     sph, objs, v, idx = random_scene()
     eye = tuple(float(x) for x in rng.uniform(-6, 6, 3)); eye = (eye[0], abs(eye[1]) + 0.2, eye[2])
-    p = pa.make_params(ref, W, H, seed=float(rng.random()), spp=2, max_bounces=3, eye=eye, target=(0.0, 1.0, 0.0))
+    depth = int(rng.random() < 0.1)
+    p = pa.make_params(ref, W, H, seed=float(rng.random()), spp=int(rng.integers(1, 4)), max_bounces=int(rng.integers(1, 6)), eye=eye,
+                       target=(0.0, 1.0, 0.0), depth=depth, fov=float(rng.choice([20.0, 60.0, 120.0])))
+    sky = skies[int(rng.integers(0, len(skies)))]
+    mats = None
+    if len(objs) and rng.random() < 0.4:       # per-object surfaces (extension), now and then with a special value in them
+        ent = []
+        for _ in range(len(objs)):
+            vals = rng.uniform(0, 1, 10).astype(np.float32)
+            if rng.random() < 0.2:
+                vals[int(rng.integers(0, 10))] = rng.choice(special)
+            ent.append((tuple(vals[0:3]), float(vals[3]), tuple(vals[4:7]), int(rng.choice([pa.PT_LOBE_PHONG, pa.PT_LOBE_GGX])), tuple(3 * vals[7:10])))
+        mats = pa.materials(ent)
     width = int(rng.choice([2, 4]))
     t.set_option("bvh_width", width)
     t.set_spheres(sph); t.set_meshes(objs, v, idx); t.set_sky(sky); t.resize(W, H)
-    orc = po.Oracle(sph, objs, v, idx, sky=sky, accel=False)
+    t.set_mesh_materials(mats)
+    orc = po.Oracle(sph, objs, v, idx, sky=sky, accel=False, materials=mats)
     t.render(p)
     c, cid, _ = orc.render(p, W, H, threads=4)
     g, gid = t.read_result(), t.read_hit_ids()
@@ -79,7 +92,7 @@ while time.time() - t0 < budget:
         objs2["m"][:, 12:15] += rng.uniform(-0.5, 0.5, (len(objs), 3)).astype(np.float32)
         t.update_transforms(objs2)
         t.render(p)
-        c2, cid2, _ = po.Oracle(sph, objs2, v, idx, sky=sky, accel=False).render(p, W, H, threads=4)
+        c2, cid2, _ = po.Oracle(sph, objs2, v, idx, sky=sky, accel=False, materials=mats).render(p, W, H, threads=4)
         g, gid, c, cid = t.read_result(), t.read_hit_ids(), c2, cid2
         ok = same(g, c) and (gid == cid).all()
     if not ok:
