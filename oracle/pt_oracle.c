@@ -737,7 +737,7 @@ static int cs_main(const PtoPrepared *p, const PtFrameParams *prm, int W, int H,
     float fspp = (float)spp;
     int maxb = prm->max_bounces;
     f3 camo = pt_make3(prm->camera_to_world[12], prm->camera_to_world[13], prm->camera_to_world[14]);
-    if (mode == 1) out4[0] = out4[1] = out4[2] = out4[3] = 0.0f; /* spp <= 0: the shader writes nothing; targets start zeroed */
+    /* _SamplesPerPixel <= 0: the loop below does not run and the thread writes nothing */
     for (int j = 1; j < spp + 1; j++) {            /* SH:839 */
         Ray ray = create_camera_ray(prm->camera_to_world, prm->camera_inverse_projection, u, v);   /* SH:848 */
         if (mode == 7 || mode == 8) {              /* SH:850-852 */
