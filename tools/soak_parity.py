@@ -17,13 +17,13 @@ from reproj_util import (gpu_pause_sequence, gpu_sequence, gpu_stripe_sequence, 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 sky = pa.procedural_sky(128, 64)
-scenes = {n: pa.Scene(n) for n in ("fixture", "xr", "blob70k")}
+scenes = {n: pa.Scene(n) for n in os.environ.get("SOAK_SCENES", "fixture,xr,blob70k").split(",")}   # e.g. SOAK_SCENES=hall260k
 oracles = {n: po.Oracle.from_scene(s, sky, accel=True) for n, s in scenes.items()}
 t = pa.PathTracer(0)
 t0 = time.time(); runs = 0; frames = 0
 while time.time() - t0 < budget:
     name = str(rng.choice(list(scenes))); s = scenes[name]; o = oracles[name]
-    W = int(rng.integers(9, 97 if name == "blob70k" else 161)); H = int(rng.integers(9, 90))
+    W = int(rng.integers(9, 97 if name in ("blob70k", "hall260k") else 161)); H = int(rng.integers(9, 90))
     mode = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12]))
     spp = 1 if mode >= 10 else int(rng.integers(1, 4)); maxb = int(rng.integers(1, 7)); n = int(rng.integers(3, 7))
     step = tuple(float(x) for x in rng.uniform(-0.3, 0.3, 3))
