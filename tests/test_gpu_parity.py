@@ -1129,3 +1129,49 @@ def test_tree_keeps_the_hits_that_only_rounding_produces(tracer, sky_small):
     far[:, :3] = aim[: n // 2] - od[: n // 2, 3:] * 5000.0
     ib, tb = tracer.trace_rays(far); ie, te = tracer.trace_rays(far, brute_force=True)
     assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
+
+
+def test_contexts_driven_from_several_threads_at_once(sky_small):
+    """A context is single-threaded, but different contexts may be driven from different threads (ctypes drops the GIL
+    during every call): four threads, each with its own context, scene, size and renderMode sequence, all running at the
+    same time, each frame checked against the oracle."""
+    import threading
+    from reproj_util import gpu_sequence, gpu_stripe_sequence, oracle_sequence, oracle_stripe_sequence
+    jobs = [("fixture", 64, 36, 2, None), ("xr", 48, 40, 0, None), ("fixture", 57, 33, 7, 3), ("blob70k", 40, 30, 10, None)]
+    wanted = []
+    for name, W, H, mode, div in jobs:
+        s = pa.Scene(name)
+        o = po.Oracle.from_scene(s, sky_small, accel=True)
+        if div:
+            wanted.append(oracle_stripe_sequence(o, s, W, H, 6, div, mode, spp=1, max_bounces=4, threads=4))
+        else:
+            wanted.append(oracle_sequence(o, s, W, H, 4, spp=1 if mode >= 10 else 2, max_bounces=4, frames_n=5, mode=mode, threads=4))
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def work(k):
+        try:
+            name, W, H, mode, div = jobs[k]
+            s = pa.Scene(name)
+            with pa.PathTracer(0) as t:
+                t.load_scene(s, sky_small); t.resize(W, H)
+                start.wait(timeout=60)
+                for _ in range(3):                                   # a few rounds, to keep the threads overlapping
+                    if div:
+                        got = gpu_stripe_sequence(t, s, W, H, 6, div, mode, spp=1, max_bounces=4)
+                    else:
+                        got = gpu_sequence(t, s, W, H, 4, spp=1 if mode >= 10 else 2, max_bounces=4, frames_n=5, mode=mode)
+                    for f, (g, w) in enumerate(zip(got, wanted[k])):
+                        for i in (0, 1):
+                            if not (g[i].view(np.uint32) == w[i].view(np.uint32)).all():
+                                errors.append(f"thread {k} ({name}, mode {mode}) frame {f} target {i} differs")
+        except Exception as e:       # noqa: BLE001 - reported by the main thread
+            errors.append(f"thread {k}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a worker thread did not finish"
+    assert not errors, errors[:5]
