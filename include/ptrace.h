@@ -157,7 +157,8 @@ const char *pt_last_error(const pt_context *ctx);
 
 /* Run on an existing hipStream_t (e.g. the caller's current stream) instead of
  * the context's own.  NULL is HIP's null stream, as everywhere in HIP;
- * PT_STREAM_OWN goes back to the stream the context created for itself. */
+ * PT_STREAM_OWN goes back to the stream the context created for itself.  The stream must stay valid
+ * for as long as it is set: pt_set_stream and pt_destroy wait for the work the context has on it. */
 #define PT_STREAM_OWN ((void *)(intptr_t)-1)
 int pt_set_stream(pt_context *ctx, void *hip_stream);
 

@@ -596,6 +596,8 @@ void pt_destroy(pt_context *ctx)
 {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
+    // renders may still be running on the caller's stream (pt_set_stream): they use the buffers freed below
+    if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
