@@ -162,3 +162,21 @@ def test_obj_loader_reads_the_reference_bunny_when_present():
     b = po.Oracle.from_scene(s, sky, accel=True).render(p, 48, 27, threads=4)
     assert (a[1] == b[1]).all() and (a[0] == b[0]).all()
     assert (a[1] > len(s.spheres)).sum() > 50            # the bunny is in view
+
+
+def test_public_headers_are_plain_c_and_keep_the_reference_layouts(tmp_path):
+    """include/ptrace.h (and the host and oracle headers) must compile as C99 and as C++11 - the boundary is a C ABI -
+    and the structs a C# host marshals must keep the reference's strides (RayTracingMaster.cs:366, 410)."""
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "include/ptrace.h"\n#include "pathtracing_amd/host/ptmaster.h"\n#include "oracle/pt_oracle.h"\n'
+                   '#include <stddef.h>\n'
+                   'int main(void) { return sizeof(PtSphere) == 56 && sizeof(PtMeshObject) == 72 && sizeof(PtCameraHistory) == 256 &&\n'
+                   '                        sizeof(PtMaterial) == 48 && offsetof(PtFrameParams, seed) == 128 ? 0 : 1; }\n')
+    exe = tmp_path / "hdr"
+    if shutil.which("gcc"):
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + root, str(src), "-o", str(exe)], check=True)
+        assert subprocess.run([str(exe)]).returncode == 0
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + root, "-x", "c++", "-fsyntax-only", str(src)], check=True)
