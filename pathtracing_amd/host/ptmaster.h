@@ -60,7 +60,8 @@ void ptm_scene_copy(const ptm_scene *s, PtSphere *spheres, PtMeshObject *objects
 /* default camera of the scene: eye, target, fov_y_deg */
 void ptm_scene_camera(const ptm_scene *s, float eye[3], float target[3], float *fov_y_deg);
 
-/* Wavefront OBJ (v / f records, polygons fan-triangulated) appended to a scene as one mesh object. */
+/* Wavefront OBJ (v / f records in every index form, polygons fan-triangulated) appended to a scene: one mesh object per
+ * "o" / "g" group that has faces.  Returns the index of the first object added, or < 0 (-1 unreadable, -2 bad index, -3 no faces). */
 int ptm_scene_add_obj(ptm_scene *s, const char *path, const float local_to_world[16]);
 
 /* ---- RayTracingMaster mirror ---------------------------------------------- */

@@ -460,9 +460,16 @@ Scene *Scene::create(const std::string &name)
 
 int Scene::add_obj(const std::string &path, const float local_to_world[16])
 {
+    // Wavefront OBJ: "v x y z" positions and "f ..." faces (index forms i, i/t, i/t/n, i//n; negative = relative to the
+    // end; polygons fan-triangulated); every "o" / "g" group with faces becomes one mesh object - the unit Unity's importer
+    // turns into a MeshFilter and RayTracingObject registers (RayTracingObject.cs) - with its own compacted vertex list,
+    // registered like RebuildMeshObjectBuffers does (RayTracingMaster.cs:387-408).  Returns the index of the first object
+    // added, or a negative number: -1 unreadable file, -2 face index out of range, -3 no faces.
     std::ifstream in(path);
     if (!in) return -1;
-    MeshBuilder mb;
+    std::vector<float> pos;                       // every "v" of the file
+    struct Group { std::vector<int> faces; };     // triangles as global vertex indices
+    std::vector<Group> groups(1);
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream ls(line);
@@ -470,24 +477,37 @@ int Scene::add_obj(const std::string &path, const float local_to_world[16])
         ls >> tag;
         if (tag == "v") {
             float x, y, z;
-            if (ls >> x >> y >> z) mb.add_vertex(x, y, z);
+            if (ls >> x >> y >> z) { pos.push_back(x); pos.push_back(y); pos.push_back(z); }
+        } else if (tag == "o" || tag == "g") {
+            if (!groups.back().faces.empty()) groups.emplace_back();
         } else if (tag == "f") {
             std::vector<int> poly;
             std::string tok;
-            int nv = (int)(mb.vertices.size() / 3);
+            const int nv = (int)(pos.size() / 3);
             while (ls >> tok) {
-                int idx = std::atoi(tok.c_str());   // "i", "i/t", "i/t/n", "i//n"
+                int idx = std::atoi(tok.c_str());
                 if (idx < 0) idx = nv + idx; else idx -= 1;
                 if (idx < 0 || idx >= nv) return -2;
                 poly.push_back(idx);
             }
             for (size_t k = 1; k + 1 < poly.size(); k++) {
-                mb.indices.push_back(poly[0]); mb.indices.push_back((int)poly[k]); mb.indices.push_back((int)poly[k + 1]);
+                groups.back().faces.push_back(poly[0]); groups.back().faces.push_back(poly[k]); groups.back().faces.push_back(poly[k + 1]);
             }
         }
     }
-    if (mb.indices.empty()) return -3;
-    return register_object(mb, local_to_world);
+    int first = -3;
+    for (const Group &g : groups) {
+        if (g.faces.empty()) continue;
+        MeshBuilder mb;
+        std::vector<int> local(pos.size() / 3, -1);           // the group's vertices, in file order
+        for (int gi : g.faces) local[(size_t)gi] = 0;
+        for (size_t v = 0; v < local.size(); v++)
+            if (local[v] == 0) local[v] = mb.add_vertex(pos[3 * v], pos[3 * v + 1], pos[3 * v + 2]);
+        for (int gi : g.faces) mb.indices.push_back(local[(size_t)gi]);
+        const int idx = register_object(mb, local_to_world);
+        if (first < 0) first = idx;
+    }
+    return first;
 }
 
 }  // namespace ptm

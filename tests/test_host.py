@@ -59,6 +59,19 @@ def test_mesh_flattening_offsets_indices_like_the_reference():
     o = s.objects[1]
     assert o["offset"] == s.objects[0]["count"] and o["count"] == 6      # quad fan-triangulated
     assert s.indices[o["offset"]:].min() == n0 and s.indices[o["offset"]:].max() == n0 + 3
+    # groups become separate mesh objects, each with the vertices it uses (in file order) and nothing else
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "two.obj")
+        open(path, "w").write("# two groups sharing one vertex pool\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 5 5 5\nv 0 0 2\n"
+                              "o first\nf 1/1/1 2/2/1 3/3/1\ng second\nf -1 -3 -4\nf 6//2 3//2 4//2\no empty\n")
+        n_obj, n_v = len(s.objects), len(s.vertices)
+        first = s.add_obj(path)
+    assert first == n_obj and len(s.objects) == n_obj + 2 and len(s.vertices) == n_v + 3 + 3       # vertex 5 is used by nobody
+    a, b = s.objects[n_obj], s.objects[n_obj + 1]
+    assert a["count"] == 3 and b["count"] == 6 and b["offset"] == a["offset"] + 3
+    v = np.asarray(s.vertices).reshape(-1, 3)
+    assert (v[s.indices[a["offset"]:a["offset"] + 3]] == [[0, 0, 0], [1, 0, 0], [1, 1, 0]]).all()
+    assert (v[s.indices[b["offset"]:b["offset"] + 6]] == [[0, 0, 2], [0, 1, 0], [1, 1, 0], [0, 0, 2], [1, 1, 0], [0, 1, 0]]).all()
 
 
 def test_blob_is_wound_outward():
