@@ -1175,3 +1175,21 @@ def test_contexts_driven_from_several_threads_at_once(sky_small):
         th.join(timeout=300)
     assert not any(th.is_alive() for th in threads), "a worker thread did not finish"
     assert not errors, errors[:5]
+
+
+def test_many_samples_and_long_paths_in_one_dispatch(tracer, fixture_scene):
+    """The lane state packs sample and bounce counters into one word (sample < 2^20, bounce < 4096): 5 000 samples per
+    pixel, and separately 300-segment paths, still match the oracle bit for bit; the limits themselves are rejected."""
+    s, orc = fixture_scene
+    W, H = 5, 3
+    tracer.resize(W, H)
+    for spp, maxb in ((5000, 3), (2, 300)):
+        p = pa.make_params(s, W, H, seed=0.25, spp=spp, max_bounces=maxb)
+        tracer.stats(); tracer.render(p)
+        g = tracer.read_result(); st = tracer.stats()
+        c, _, cst = orc.render(p, W, H, threads=4)
+        _assert_same_image(g, c, f"spp={spp} max_bounces={maxb}")
+        assert st["rays"] == cst["rays"] and st["paths"] == W * H * spp
+    for bad in (dict(spp=1 << 20), dict(max_bounces=4096)):
+        with pytest.raises(pa.PtraceError):
+            tracer.render(pa.make_params(s, W, H, **bad))
