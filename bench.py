@@ -107,10 +107,11 @@ def valu_view(solo, launches, kernel_ms):
 def measured_traffic(args):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes, when they were
     taken on this workload; None otherwise (bench.py cannot run the profiler on itself)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path) or (args.scene, args.width, args.height, args.spp, args.bounces) != ("hall260k", 1920, 1080, 16, 8):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))      # the most recent one
+    if not found or (args.scene, args.width, args.height, args.spp, args.bounces) != ("hall260k", 1920, 1080, 16, 8):
         return None
-    t = json.load(open(path))
+    t = json.load(open(found[-1]))
     return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
 
 
