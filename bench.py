@@ -119,6 +119,8 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "PTRACE_BENCH_DEVICE" in os.environ:        # rehearsals of the N > 1 path on a box with fewer GPUs than ranks
+        local_rank = int(os.environ["PTRACE_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
@@ -132,7 +134,22 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # "nccl" is RCCL.  PTRACE_BENCH_BACKEND=gloo (with PTRACE_BENCH_DEVICE) rehearses the N > 1 code on a box with one GPU,
+        # where RCCL refuses two ranks on one device; the collectives then go through host memory.
+        backend = os.environ.get("PTRACE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def collective(fn, tensor, **kw):
+        """One collective on a CUDA tensor: directly on RCCL, through a host copy on the rehearsal backend."""
+        if dist.get_backend() == "nccl":
+            fn(tensor, **kw)
+        else:
+            host = tensor.cpu()
+            fn(host, **kw)
+            tensor.copy_(host)
 
     W, H = args.width, args.height
     scene = pa.Scene(args.scene)
@@ -171,7 +188,7 @@ def main():
         for i in range(used):
             total.add_(accums[i])
         if dist is not None:
-            dist.reduce(total, dst=0, op=dist.ReduceOp.SUM)
+            collective(dist.reduce, total, dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
         if dist is not None:
@@ -202,8 +219,8 @@ def main():
     t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["rays"], st["nodes_visited"], st["prims_tested"], st["paths"]], dtype=torch.float64, device="cuda")
     if dist is not None:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        collective(dist.all_reduce, t_all, op=dist.ReduceOp.MAX)
+        collective(dist.all_reduce, counts, op=dist.ReduceOp.SUM)
     dt = float(t_all.item())
     rays, nodes, prims, paths = [float(x) for x in counts.tolist()]
 
