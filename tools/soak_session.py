@@ -61,6 +61,7 @@ while time.time() - t0 < budget:
     if rng.random() < 0.05:
         divisions = int(rng.integers(1, 6))
     eye = eye + rng.uniform(-0.15, 0.15, 3)
+    eye = np.clip(eye, (-15.0, 0.2, -15.0), (15.0, 12.0, 15.0))      # a random walk, but one that keeps the scene in reach
     depth = int(rng.random() < 0.05)
     p = pa.make_params(scene, W, H, seed=float(rng.random()), spp=1 if mode >= 10 else int(rng.integers(1, 3)), max_bounces=int(rng.integers(1, 5)),
                        eye=tuple(eye), target=tuple(scene.target), render_mode=mode, accumulation_frames=int(rng.integers(1, 9)),
