@@ -1177,10 +1177,11 @@ def test_contexts_driven_from_several_threads_at_once(sky_small):
     assert not errors, errors[:5]
 
 
-def test_many_samples_and_long_paths_in_one_dispatch(tracer, fixture_scene):
+def test_many_samples_and_long_paths_in_one_dispatch(tracer, fixture_scene, sky_small):
     """The lane state packs sample and bounce counters into one word (sample < 2^20, bounce < 4096): 5 000 samples per
     pixel, and separately 300-segment paths, still match the oracle bit for bit; the limits themselves are rejected."""
     s, orc = fixture_scene
+    tracer.load_scene(s, sky_small); tracer.set_mesh_materials(None)      # the shared context may hold another test's scene
     W, H = 5, 3
     tracer.resize(W, H)
     for spp, maxb in ((5000, 3), (2, 300)):
