@@ -23,11 +23,20 @@ def _assert_same_image(gpu, cpu, what):
                           f"gpu={gpu[tuple(np.argwhere(neq)[0])]} cpu={cpu[tuple(np.argwhere(neq)[0])]}"
 
 
-@pytest.fixture(scope="module")
+_FIXTURE = {}
+
+
+@pytest.fixture
 def fixture_scene(tracer, sky_small):
-    s = pa.Scene("fixture")
-    tracer.load_scene(s, sky_small)
-    return s, po.Oracle.from_scene(s, sky_small, accel=False)
+    """The 20-sphere + 320-triangle scene, loaded into the shared context for every test that asks for it (other tests
+    leave their own scenes, materials and options behind), with its exhaustive-loop oracle built once."""
+    if not _FIXTURE:
+        s = pa.Scene("fixture")
+        _FIXTURE["scene"] = s; _FIXTURE["oracle"] = po.Oracle.from_scene(s, sky_small, accel=False)
+    tracer.load_scene(_FIXTURE["scene"], sky_small)
+    tracer.set_mesh_materials(None)
+    tracer.set_option("reuse_primary_hit", 0)
+    return _FIXTURE["scene"], _FIXTURE["oracle"]
 
 
 @pytest.mark.parametrize("spp,maxb", [(1, 4), (1, 8), (4, 8), (16, 4)])
