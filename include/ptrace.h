@@ -80,7 +80,7 @@ typedef struct PtMaterial {
 
 /* Accumulation of the fresh frame into the converged image. */
 enum {
-    PT_ACCUM_NONE = 0,   /* Result only                                                            */
+    PT_ACCUM_NONE = 0,   /* no accumulation (converged = the previous Result, as the shader leaves it) */
     PT_ACCUM_MEAN = 1,   /* converged = converged*(1 - 1/(S+1)) + fresh/(S+1), all four channels   */
     PT_ACCUM_SUM = 2,    /* converged += fresh (S == 0: converged = fresh); for sample sharding     */
     PT_ACCUM_ADDMAT = 3  /* AddMat.shader:44-63 with its SrcAlpha/OneMinusSrcAlpha blend (:11)      */
@@ -228,6 +228,11 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr);
 
 /* SetShaderParameters + Dispatch(0, ceil(W/32), ceil(H/32), 1)
  * (RayTracingMaster.cs:716,745-747).
+ *
+ * renderMode 1 (RayTracingShader.compute:728-731,822-874,933-936): plain path tracing into Result.  Like the shader,
+ * the dispatch first copies the previous content of Result into Result1 (the converged target) over the dispatched
+ * rectangle - renderMode 1 never reads it, a later frame in renderMode 5..8, 11 or 12 does.  With accumulate !=
+ * PT_ACCUM_NONE the converged target holds the accumulation instead and that copy is not made.
  *
  * renderMode 2 (RayTracingShader.compute:728-731,950-983): Result1 - the converged target - first
  * receives the previous content of Result over the dispatched rectangle, as one copy that is complete

@@ -905,9 +905,11 @@ int pto_render_history(const PtoPrepared *p, const PtFrameParams *prm, const PtC
     if (threads <= 0) threads = 1;
     const int screen_passes = mode == 0 && prm->depth != 1 && prm->samples_per_pixel > 0;
     /* SH:728-736 for every dispatched thread, before any of them goes on: Result1 = Result2 (renderMode 0) or
-     * Result1 = Result (renderMode 2, 3, 4, 10; renderMode 1 too in the shader, where Result1 is not read and
-     * the accumulation owns that target) */
-    if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10) {
+     * Result1 = Result (renderMode 1, 2, 3, 4, 10).  renderMode 1 itself never reads Result1; the copy matters to
+     * the modes that show Result1 without copying first (5..8, 11, 12) when the host switches to them.  It is left
+     * out when the caller has no Result1 (pto_render) or accumulates into it (an extension: the shader has no
+     * accumulation, AddMat.shader runs after it on another target). */
+    if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10 || (mode == 1 && result1 && prm->accumulate == PT_ACCUM_NONE)) {
         const float *src = mode == 0 ? result2 : result;
         for (int y = y0; y < y0 + th; y++)
             memcpy(result1 + 4 * ((size_t)y * W + x0), src + 4 * ((size_t)y * W + x0), (size_t)tw * 4 * sizeof(float));

@@ -230,7 +230,7 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
         }
         out.nodes4.push_back(w);
         out.depth4 = 1;
-        return out;
+        return out;                      // a single leaf: nothing is ever stacked
     }
     out.nodes.reserve((size_t)b.next.load());
     struct Item { int32_t tmp_index; int32_t parent; int side; };
@@ -255,11 +255,12 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
         if (!l.count) stack.push_back({t.left, me, 0});
     }
     out.depth += 1;
+    out.stack_need2 = out.depth;         // one sibling per inner node on the way down
 
     // ---- collapse to four children per node: repeatedly open the inner child with the largest area
-    struct Item4 { int32_t tmp_index; int32_t parent; int slot; int depth; };
+    struct Item4 { int32_t tmp_index; int32_t parent; int slot; int depth; int stacked; };   // stacked: entries held when the node is entered
     std::vector<Item4> st4;
-    st4.push_back({root, -1, 0, 1});
+    st4.push_back({root, -1, 0, 1, 0});
     out.nodes4.reserve(out.nodes.size() / 2 + 1);
     while (!st4.empty()) {
         Item4 it = st4.back(); st4.pop_back();
@@ -317,8 +318,9 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
         out.nodes4.push_back(nd);
         if (it.parent >= 0) out.nodes4[it.parent].child[it.slot] = me;
         out.depth4 = std::max(out.depth4, it.depth);
+        out.stack_need4 = std::max(out.stack_need4, it.stacked + nk - 1);
         for (int k = nk - 1; k >= 0; k--)
-            if (!tmp[kids[k]].count) st4.push_back({kids[k], me, k, it.depth + 1});
+            if (!tmp[kids[k]].count) st4.push_back({kids[k], me, k, it.depth + 1, it.stacked + nk - 1});
     }
     for (Bvh4Node &nd : out.nodes4) {
         int32_t spare = nd.child[0];

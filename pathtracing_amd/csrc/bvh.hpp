@@ -60,6 +60,10 @@ struct BvhResult {
     int depth4 = 0;
     std::vector<uint32_t> order;      // order[k] = input primitive index of reordered slot k
     int depth = 0;
+    // Most traversal-stack entries a ray can hold at once: on its way down a ray that enters every child of every node
+    // stacks all siblings of the child it follows (children - 1 per node).  stack_need2 <= depth <= kMaxDepth + 1; the
+    // four-wide tree's figure depends on how the collapse fell and can approach 3 * kMaxDepth for lopsided trees.
+    int stack_need2 = 0, stack_need4 = 0;
 };
 
 // boxes: one (already padded) box per primitive.  leaf_size <= kMaxLeafPrims.

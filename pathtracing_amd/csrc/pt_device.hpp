@@ -109,8 +109,10 @@ constexpr int kWorkShards = 64;        // most counters a frame is split over: o
 constexpr int kWorkStride = 16;        // u32 words between counters: one cache line each
 constexpr int kStackLds = 12;          // traversal stack entries kept in LDS per lane: with the path kernel's other LDS arrays that
                                        // is 31 KB per block, so five blocks fit the 160 KB of a CU
-constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 92 >= the deepest stack:
-                                       // kMaxDepth (60) pushes for two-child nodes, 3 * ceil(60 / 2) for four-child nodes
+constexpr int kStackOverflow = 80;     // further entries in a global buffer.  Capacity 92: a two-child tree stacks one entry per
+                                       // level (<= kMaxDepth + 1 = 61); a four-child tree up to three per level, which a lopsided
+                                       // collapse can push past 92 - the host measures each tree's worst case (BvhResult::stack_need4)
+                                       // and walks the two-child tree instead when it does not fit
 constexpr int kDoneNode = (int)0x80000000;   // traversal state "stack empty: ray finished"
 
 __device__ __forceinline__ float as_f(int32_t i) { return __int_as_float(i); }
@@ -133,7 +135,7 @@ __device__ __forceinline__ void stack_push(const Stack &s, int &sp, int32_t v)
 {
     if (sp < kStackLds) s.lds[sp * kBlock] = (uint32_t)v;
     else if (sp < kStackLds + kStackOverflow) s.overflow[(size_t)(sp - kStackLds) * s.stride] = (uint32_t)v;
-    sp++;  // beyond capacity the entry is dropped; the builder's depth bound makes that unreachable
+    sp++;  // beyond capacity the entry would be dropped; the host never launches on a tree that can get there
 }
 __device__ __forceinline__ int32_t stack_pop(const Stack &s, int &sp)
 {

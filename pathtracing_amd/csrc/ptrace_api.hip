@@ -68,6 +68,8 @@ struct pt_context {
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_sphere_mat = nullptr, *d_sky = nullptr;
     uint32_t *d_by_id = nullptr;
     int n_nodes4 = 0, bvh_width = 4;
+    int stack_need4 = 0;                           // most stack entries a ray can hold in the four-wide tree of the last build
+    int stack_limit = kStackLds + kStackOverflow;  // entries a lane's stack holds; PTRACE_STACK_LIMIT lowers it (tests of the fallback)
     int n_nodes = 0, n_prims = 0, n_spheres = 0, sky_w = 0, sky_h = 0;
 
     // targets
@@ -133,6 +135,14 @@ __global__ __launch_bounds__(256) void add_image_kernel(float4 *dst, const float
 namespace {
 
 thread_local std::string g_create_error;
+
+// The tree the kernels walk: the four-wide one unless a ray could need more stack entries in it than a lane has (a lopsided
+// tree after the collapse: up to three stacked siblings per level).  The two-child tree stacks one entry per level, and its
+// depth is bounded by kMaxDepth, so it always fits.
+int tree_width(const pt_context *ctx)
+{
+    return ctx->bvh_width == 4 && ctx->stack_need4 <= ctx->stack_limit ? 4 : 2;
+}
 
 int fail(pt_context *ctx, int code, const std::string &msg)
 {
@@ -369,9 +379,11 @@ int rebuild_scene(pt_context *ctx)
     ctx->n_nodes = (int)bvh.nodes.size();
     ctx->n_prims = (int)nP;
     ctx->n_spheres = nS;
-    ctx->stats.bvh_nodes = ctx->bvh_width == 4 ? ctx->n_nodes4 : ctx->n_nodes;
+    ctx->stack_need4 = bvh.stack_need4;
+    static_assert(kMaxDepth + 1 <= kStackLds + kStackOverflow, "the two-child tree must always fit the traversal stack");
+    ctx->stats.bvh_nodes = tree_width(ctx) == 4 ? ctx->n_nodes4 : ctx->n_nodes;
     ctx->stats.bvh_prims = ctx->n_prims;
-    ctx->stats.bvh_depth = ctx->bvh_width == 4 ? bvh.depth4 : bvh.depth;
+    ctx->stats.bvh_depth = tree_width(ctx) == 4 ? bvh.depth4 : bvh.depth;
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING"))
@@ -383,12 +395,27 @@ int rebuild_scene(pt_context *ctx)
     return PT_OK;
 }
 
+// How far from a ray origin (`n` points, `stride` floats apart) the far side of the scene lies: what the sphere boxes must
+// have been inflated for (pt_context::sphere_reach).
+float reach_needed(const pt_context *ctx, const float *origins, int n, int stride)
+{
+    float c[3], half = 0.0f, need = 0.0f;
+    for (int k = 0; k < 3; k++) { c[k] = 0.5f * (ctx->scene_lo[k] + ctx->scene_hi[k]); const float e = ctx->scene_hi[k] - ctx->scene_lo[k]; half += e * e; }
+    half = 0.5f * std::sqrt(half);
+    for (int i = 0; i < n; i++) {
+        const float *o = origins + (size_t)i * stride;
+        const float d = std::sqrt((o[0] - c[0]) * (o[0] - c[0]) + (o[1] - c[1]) * (o[1] - c[1]) + (o[2] - c[2]) * (o[2] - c[2])) + half;
+        if (std::isfinite(d)) need = std::max(need, d);
+    }
+    return std::max(need, 2.0f * half);          // rays that start inside the (possibly refitted) scene
+}
+
 // The scene as the next launch needs it: rebuilt if something changed, and rebuilt once more with a larger reach if a ray
 // origin (a camera; `n` points, `stride` floats apart) lies farther from the scene than the sphere boxes were inflated for.
 int rebuild_scene(pt_context *ctx);
 int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
 {
-    if (ctx->bvh_width == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
+    if (tree_width(ctx) == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
     for (int pass = 0; pass < 2; pass++) {
         if (ctx->scene_dirty) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -396,15 +423,7 @@ int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
             if (rc) return rc;
         }
         if (ctx->spheres.empty()) break;
-        float c[3], half = 0.0f, need = 0.0f;
-        for (int k = 0; k < 3; k++) { c[k] = 0.5f * (ctx->scene_lo[k] + ctx->scene_hi[k]); const float e = ctx->scene_hi[k] - ctx->scene_lo[k]; half += e * e; }
-        half = 0.5f * std::sqrt(half);
-        for (int i = 0; i < n; i++) {
-            const float *o = origins + (size_t)i * stride;
-            const float d = std::sqrt((o[0] - c[0]) * (o[0] - c[0]) + (o[1] - c[1]) * (o[1] - c[1]) + (o[2] - c[2]) * (o[2] - c[2])) + half;
-            if (std::isfinite(d)) need = std::max(need, d);
-        }
-        need = std::max(need, 2.0f * half);          // rays that start inside the (possibly refitted) scene
+        const float need = reach_needed(ctx, origins, n, stride);
         if (!(need > ctx->sphere_reach)) break;
         ctx->sphere_reach_request = 2.0f * need;
         ctx->scene_dirty = true;
@@ -496,7 +515,7 @@ int render_wavefront(pt_context *ctx, RenderArgs &a)
         a.iter = (int32_t)it;
         a.q_in = (it & 1) ? qb : qa;
         a.q_out = (it & 1) ? qa : qb;
-        if (ctx->bvh_width == 4) hipLaunchKernelGGL(wf_trace<4>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
+        if (tree_width(ctx) == 4) hipLaunchKernelGGL(wf_trace<4>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(wf_trace<2>, dim3(trace_grid), dim3(kBlock), 0, ctx->stream, a);
         hipLaunchKernelGGL(wf_shade, dim3(shade_grid), dim3(kBlock), 0, ctx->stream, a);
     }
@@ -580,10 +599,14 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->sched_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_mat_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched_ext_blocks_per_cu = std::max(1, bpc);
-    if (const char *env = std::getenv("PTRACE_BACKEND"))
-        ctx->backend = std::strcmp(env, "mega") == 0 ? 0 : 1;
+    if (const char *env = std::getenv("PTRACE_BACKEND")) {
+        if (std::strcmp(env, "sched") == 0 || std::strcmp(env, "mega") == 0) ctx->backend = 0;
+        else if (std::strcmp(env, "wavefront") == 0 || std::strcmp(env, "wave") == 0) ctx->backend = 1;
+        else std::fprintf(stderr, "libptrace: PTRACE_BACKEND=%s ignored (sched | wavefront)\n", env);
+    }
     if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : 4;
+    if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_NODE")) ctx->vote_node = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE")) ctx->node_vote = std::max(1, std::min(64, std::atoi(env)));
@@ -691,7 +714,7 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
             objects[o].indices_count != ctx->objects[o].indices_count)
             return fail(ctx, PT_ERR_INVALID, "pt_update_transforms: index ranges differ from pt_set_meshes");
     ctx->objects.assign(objects, objects + n_objects);
-    if (!ctx->refit || !ctx->refit_ready || ctx->scene_dirty || ctx->bvh_width != 4 || n_objects == 0) {
+    if (!ctx->refit || !ctx->refit_ready || ctx->scene_dirty || tree_width(ctx) != 4 || n_objects == 0) {
         ctx->scene_dirty = true;      // full build at the next render
         return PT_OK;
     }
@@ -759,6 +782,13 @@ int pt_resize(pt_context *ctx, int width, int height)
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool rebind_r = ctx->result == ctx->own_result, rebind_c = ctx->conv == ctx->own_conv,
                rebind_i = ctx->ids == ctx->own_ids, rebind_2 = ctx->result2 == ctx->own_result2;
+    // Until every new buffer exists the context has no targets: a failure below leaves it in the state "before pt_resize"
+    // (W == 0), not pointing at freed memory.  Caller-owned targets stay bound.
+    if (rebind_r) ctx->result = nullptr;
+    if (rebind_c) ctx->conv = nullptr;
+    if (rebind_i) ctx->ids = nullptr;
+    if (rebind_2) ctx->result2 = nullptr;
+    ctx->W = ctx->H = 0;
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     if (ctx->display == ctx->own_display) ctx->display = nullptr;
@@ -808,7 +838,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     const int tiles_y = (th + 7) / 8;
     a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
     const bool extended = ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
-    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary) return render_wavefront(ctx, a);
+    // the wavefront stages pack a path's bounce count into 8 bits (pt_wavefront.hpp): longer paths go to the scheduled kernel
+    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary && a.maxb <= 255) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
     {
         // Few samples per pixel: pixels are claimed often, and one counter would serialise the claims at the L2.  Many
@@ -829,10 +860,10 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     a.stack_overflow = ctx->d_stack_ovf;
     a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
     if (extended) {
-        if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_mat_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
-        if (ctx->bvh_width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     }
     PT_HIP(ctx, hipGetLastError());
@@ -851,7 +882,7 @@ static int launch_primary(pt_context *ctx, RenderArgs &a, int what, int x0, int 
     const int grid = (int)std::min<int64_t>(((int64_t)a.total_items + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8 * 4);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
-    if (ctx->bvh_width == 4) hipLaunchKernelGGL(primary_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
+    if (tree_width(ctx) == 4) hipLaunchKernelGGL(primary_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
     else hipLaunchKernelGGL(primary_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
@@ -870,9 +901,22 @@ static int ensure_screen_scratch(pt_context *ctx)
     return PT_OK;
 }
 
+static int render_frame(pt_context *ctx, const PtFrameParams *p);
+
 int pt_render(pt_context *ctx, const PtFrameParams *p)
 {
     if (!ctx) return PT_ERR_INVALID;
+    const int rc = render_frame(ctx, p);
+    if (rc != PT_OK && ctx->epoch_open) {
+        // the statistics epoch must end in a recorded event whatever happened after it opened
+        DeviceGuard g(ctx->device);
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+    }
+    return rc;
+}
+
+static int render_frame(pt_context *ctx, const PtFrameParams *p)
+{
     if (!p) return fail(ctx, PT_ERR_INVALID, "pt_render: params is NULL");
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_render before pt_resize");
     const int mode = p->render_mode;
@@ -907,9 +951,11 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         if ((rc = ensure_scene(ctx, cams, n_cams, 3))) return rc;
     }
     const size_t pitch = (size_t)ctx->W * sizeof(float4);
-    if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10) {
-        // SH:728-736, Result1 = Result (renderMode 2, 3, 4, 10) or Result2 (renderMode 0) over the dispatched
-        // rectangle, finished before any pixel is traced
+    if (mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 10 || (mode == 1 && p->accumulate == PT_ACCUM_NONE)) {
+        // SH:728-736, Result1 = Result (renderMode 1, 2, 3, 4, 10) or Result2 (renderMode 0) over the dispatched
+        // rectangle, finished before any pixel is traced.  renderMode 1 does not read Result1, but a later switch to a
+        // mode that shows it without copying first (5..8, 11, 12) does.  With an accumulation mode the converged target
+        // belongs to the accumulation (an extension: the shader has none) and is not overwritten.
         const float4 *src = mode == 0 ? ctx->result2 : ctx->result;
         PT_HIP(ctx, hipMemcpy2DAsync(ctx->conv + (size_t)y0 * ctx->W + x0, pitch, src + (size_t)y0 * ctx->W + x0, pitch,
                                      (size_t)tw * sizeof(float4), (size_t)th, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1203,7 +1249,7 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     SceneDev sc = scene_dev(ctx);
     if (brute_force)
         hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
-    else if (ctx->bvh_width == 4)
+    else if (tree_width(ctx) == 4)
         hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     else
         hipLaunchKernelGGL(trace_rays_bvh_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);

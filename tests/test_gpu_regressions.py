@@ -1,0 +1,90 @@
+"""Regression cases found by the randomised soaks (tools/soak_*.py), replayed as fixed sequences."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pathtracing_amd as pa
+from oracle import pt_oracle as po
+from pathtracing_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+def test_master_mirror_keeps_its_targets_when_the_size_does_not_change():
+    """Three frames a run of tools/soak_master.py recorded as a mismatch (camera below the ground plane, renderMode 4
+    with _Depth, renderMode 4, renderMode 3; 57x22, then 35x39 twice).  The third frame followed a "resize" to the size
+    the targets already had: InitRenderTexture (RayTracingMaster.cs:545) then keeps the targets, so renderMode 3's
+    prologue copy (RayTracingShader.compute:728-731) puts the second frame into Result1.  The soak's model had made fresh,
+    zeroed targets instead - the disagreement was the model's, not the library's or the mirror's.  Here the model keeps
+    its targets and all three targets of all three frames must be identical."""
+    lib = _ffi.ptmaster(); pt = _ffi.ptrace()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        assert lib.ptm_master_load_scene(h, s.handle, 64, 32) == 0, lib.ptm_master_error(h)
+        orc = po.Oracle.from_scene(s, pa.procedural_sky(64, 32), accel=True)
+        ctx = lib.ptm_master_context(h)
+        lib.ptm_master_set_divisions(h, 3)
+        # (W, H, renderMode, _Depth, spp, bounces, _AccumulationFrames, eye); two frames first so that _Counter is 2, 0, 1
+        frames = [(57, 22, 2, 0, 1, 2, 4, (5.9, -14.2, 8.1)), (57, 22, 4, 0, 1, 2, 4, (5.9, -14.25, 8.15)),
+                  (57, 22, 4, 1, 1, 2, 2, (5.838001251220703, -14.280645370483398, 8.194798469543457)),
+                  (35, 39, 4, 0, 1, 2, 8, (5.768211364746094, -14.37048053741455, 8.319742202758789)),
+                  (35, 39, 3, 0, 2, 1, 6, (5.678927898406982, -14.240138053894043, 8.398101806640625))]
+        size = None; old = []; cams = [pa.PtCameraHistory() for _ in range(100)]
+        counters = []
+        for k, (W, H, mode, depth, spp, maxb, accf, eye) in enumerate(frames):
+            if (W, H) != size:
+                size = (W, H)
+                res = np.zeros((H, W, 4), np.float32); res1 = np.zeros_like(res); res2 = np.zeros_like(res)
+            lib.ptm_master_configure(h, W, H, spp, maxb, depth, pa.PT_ACCUM_NONE, accf)      # every frame, as the soak does
+            lib.ptm_master_set_render_mode(h, mode)
+            lib.ptm_master_set_camera(h, (C.c_float * 3)(*eye), (C.c_float * 3)(*s.target), C.c_float(s.fov), C.c_float(0.0))
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            counters.append(p.counter)
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            cams[:len(old)] = old
+            orc.render_history(p, cams, W, H, res, res1, threads=4, result2=res2)
+            old = [pa.camera_history_entry(eye, tuple(s.target), s.fov, W / H)]              # modes 2 .. 4: the list restarts every frame
+            got = [np.empty((H, W, 4), np.float32) for _ in range(3)]
+            assert pt.pt_read_result(ctx, got[0].ctypes.data) == 0 and pt.pt_read_converged(ctx, got[1].ctypes.data) == 0
+            assert pt.pt_read_target(ctx, pa.PT_TARGET_DENOISED, got[2].ctypes.data) == 0
+            for name, a, b in (("Result", got[0], res), ("Result1", got[1], res1), ("Result2", got[2], res2)):
+                assert _same(a, b), f"frame {k}: {name} differs"
+        assert counters == [0, 1, 2, 0, 1]
+        assert res1[..., 3].min() > 10.0        # the history of the last frame is the frame before it, not zeros
+    finally:
+        lib.ptm_master_destroy(h)
+
+
+def test_tree_that_could_overflow_the_stack_is_walked_as_a_two_child_tree(monkeypatch):
+    """A four-wide tree stacks up to three siblings per level; when its worst case (BvhResult::stack_need4) exceeds what a
+    lane's stack holds, the library walks the two-child tree of the same build instead.  PTRACE_STACK_LIMIT = 20 makes the
+    70 k-triangle scene (worst case 33) such a tree: same image and hits as the oracle, statistics of the binary tree."""
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(64, 32)
+    W, H = 96, 54
+    p = pa.make_params(s, W, H, seed=0.5, spp=2, max_bounces=6)
+    want, want_ids, _ = po.Oracle.from_scene(s, sky, accel=True).render(p, W, H, threads=8)
+    nodes = {}
+    for limit in (None, "20"):
+        if limit:
+            monkeypatch.setenv("PTRACE_STACK_LIMIT", limit)
+        t = pa.PathTracer(0)
+        try:
+            t.load_scene(s, sky); t.resize(W, H); t.render(p)
+            assert _same(t.read_result(), want) and (t.read_hit_ids() == want_ids).all()
+            rng = np.random.default_rng(5)
+            od = np.zeros((3000, 6), np.float32); od[:, :3] = rng.uniform(-4, 4, (3000, 3)); od[:, 1] = np.abs(od[:, 1]) + 3
+            d = rng.normal(0, 1, (3000, 3)); d[:, 1] = -np.abs(d[:, 1]); od[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+            ib, tb = t.trace_rays(od); ie, te = t.trace_rays(od, brute_force=True)
+            assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
+            nodes[limit] = t.stats()["bvh_nodes"]
+        finally:
+            t.close()
+    assert nodes["20"] > 1.5 * nodes[None]          # the two-child tree has about twice the nodes

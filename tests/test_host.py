@@ -1,12 +1,15 @@
 """Host side above the C ABI: scene procedure (RayTracingMaster.cs:315-369), mesh flattening
 (:371-413), camera matrices (:489-490) and the master's per-frame parameters (:455-540)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import pathtracing_amd as pa
 from pathtracing_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_sphere_field_procedure():
@@ -193,3 +196,20 @@ def test_public_headers_are_plain_c_and_keep_the_reference_layouts(tmp_path):
         assert subprocess.run([str(exe)]).returncode == 0
     if shutil.which("g++"):
         subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + root, "-x", "c++", "-fsyntax-only", str(src)], check=True)
+
+
+def test_bvh_builder_invariants_and_stack_bound(tmp_path):
+    """tools/bvh_check.cpp (host only, under AddressSanitizer + UBSan): on named scenes and on degenerate inputs every
+    primitive sits in exactly one leaf, every dequantised box holds what lies below it, and the builder's worst-case
+    traversal-stack figure for the four-wide tree equals an independent walk of the tree - the figure the library uses to
+    decide whether a lane's 92-entry stack can take that tree ("4000 points on a line" needs 126 and must not)."""
+    import subprocess
+    exe = str(tmp_path / "bvh_check")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-I", "include", "-I", "pathtracing_amd/csrc",
+           "-I", "pathtracing_amd/host", "tools/bvh_check.cpp", "pathtracing_amd/csrc/bvh.cpp", "pathtracing_amd/host/scene_gen.cpp",
+           "-lpthread", "-o", exe]
+    subprocess.run(cmd, cwd=ROOT, check=True)
+    out = subprocess.run([exe], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "bvh_check ok" in out.stdout, out.stdout + out.stderr
+    need = {ln.split("  ")[0].strip(): int(ln.split("stack need")[1].split("/")[1].split(",")[0]) for ln in out.stdout.splitlines() if "stack need" in ln}
+    assert need["4000 points on a line"] > 92 and need["hall260k leaf 2"] < 60

@@ -34,19 +34,23 @@ static int check(const char *what, const std::vector<Aabb> &boxes, int leaf)
     for (int c : seen) if (c != 1) bad++;
     // four-wide layout: walk it, dequantise, test containment of every primitive of a leaf and count leaf coverage
     std::vector<int> cover(n, 0);
-    struct It { int32_t node; int depth; };
-    std::vector<It> st{{0, 1}};
-    int depth = 0;
+    struct It { int32_t node; int depth; int stacked; };
+    std::vector<It> st{{0, 1, 0}};
+    int depth = 0, need4 = 0;
     while (!st.empty()) {
         It it = st.back(); st.pop_back();
         depth = std::max(depth, it.depth);
+        int kids = 0;
+        for (int k = 0; k < 4; k++) kids += (r.nodes4[(size_t)it.node].valid >> k) & 1;
+        const int held = it.stacked + kids - 1;      // a ray that enters every child stacks all siblings of the one it follows
+        if (n > 1) need4 = std::max(need4, held);
         const ptrace::Bvh4Node &nd = r.nodes4[(size_t)it.node];
         const float cell[3] = {std::ldexp(1.0f, nd.ex - 127), std::ldexp(1.0f, nd.ey - 127), std::ldexp(1.0f, nd.ez - 127)};
         for (int k = 0; k < 4; k++) {
             if (!((nd.valid >> k) & 1)) continue;
             float lo[3], hi[3];
             for (int a = 0; a < 3; a++) { lo[a] = nd.org[a] + nd.qlo[a][k] * cell[a]; hi[a] = nd.org[a] + nd.qhi[a][k] * cell[a]; }
-            if (nd.child[k] >= 0) { st.push_back({nd.child[k], it.depth + 1}); continue; }
+            if (nd.child[k] >= 0) { st.push_back({nd.child[k], it.depth + 1, held}); continue; }
             uint32_t enc = (uint32_t)~nd.child[k], first = enc >> 3, count = (enc & 7u) + 1u;
             for (uint32_t s = first; s < first + count; s++) {
                 if (s >= n) { bad++; continue; }
@@ -56,9 +60,10 @@ static int check(const char *what, const std::vector<Aabb> &boxes, int leaf)
         }
     }
     for (int c : cover) if (c != 1) bad++;
-    if (depth > ptrace::kMaxDepth || r.depth > ptrace::kMaxDepth) bad++;
-    std::printf("%-28s %8zu prims: %7zu nodes, %7zu wide nodes, depth %2d / %2d, %s\n", what, n, r.nodes.size(), r.nodes4.size(), r.depth,
-                depth, bad ? "INVALID" : "ok");
+    if (depth > ptrace::kMaxDepth || r.depth > ptrace::kMaxDepth + 1) bad++;
+    if (need4 != r.stack_need4 || r.stack_need2 > ptrace::kMaxDepth + 1 || r.stack_need4 > 3 * depth) bad++;
+    std::printf("%-28s %8zu prims: %7zu nodes, %7zu wide nodes, depth %2d / %2d, stack need %2d / %3d, %s\n", what, n, r.nodes.size(),
+                r.nodes4.size(), r.depth, depth, r.stack_need2, r.stack_need4, bad ? "INVALID" : "ok");
     return bad;
 }
 
@@ -100,6 +105,14 @@ int main()
       bad += check("random + two huge boxes", b, 2); }
     { std::vector<Aabb> b; for (int i = 0; i < 20000; i++) { float s = std::ldexp(1.0f, -(i % 40)); b.push_back(point_box(s, s, s, s * 0.25f)); }
       bad += check("geometric sizes (deep tree)", b, 1); }
+    { // a comb: at every scale a cluster of four wide boxes beside everything smaller; the collapse opens the cluster
+      // (largest area) and the rest of the scene advances one level per wide node, three stacked siblings each
+      std::vector<Aabb> b;
+      for (int k = 0; k < 56; k++) {
+          const float s = std::ldexp(1.0f, -k);
+          for (int j = 0; j < 4; j++) { Aabb bx = {{s * (0.55f + 0.1f * j), -3 * s, -3 * s}, {s * (0.6f + 0.1f * j), 3 * s, 3 * s}}; b.push_back(bx); }
+      }
+      bad += check("comb of clusters (lopsided)", b, 1); }
     { std::vector<Aabb> b; for (int i = 0; i < 2000; i++) b.push_back(point_box(u(rng) * 1e30f, u(rng) * 1e-30f, u(rng), 1e20f)); bad += check("huge and tiny extents", b, 2); }
     std::printf(bad ? "bvh_check FAILED (%d)\n" : "bvh_check ok\n", bad);
     return bad != 0;
