@@ -313,6 +313,19 @@ int pt_get_stats(pt_context *ctx, PtStats *out);
 int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays,
                   int brute_force, int32_t *ids_out, float *t_out);
 
+/* pt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as pt_trace_rays,
+ * but the call makes no hipMalloc / hipFree: the device copies of the rays and of the results and the traversal
+ * stack's overflow area live in one array of 11.5 MB (352 bytes per ray) that is part of the library's device image -
+ * every GPU the library runs on holds it until the process ends.  Limits: n_rays <= PT_TRACE_RAYS_STATIC_MAX
+ * (PT_ERR_INVALID beyond); the scene must have been built by an earlier pt_render or pt_trace_rays and not changed
+ * since, and no ray may start farther from it than that build allowed for (PT_ERR_INVALID says which; the remedy is
+ * one ordinary pt_trace_rays call, which rebuilds).  All contexts on a GPU share the array: calls that overlap on one
+ * GPU - from different contexts or threads - race; calls on different GPUs do not. */
+#define PT_TRACE_RAYS_STATIC_MAX 32768
+int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
+                         int brute_force, int32_t *ids_out, float *t_out);
+
 const char *pt_version(void);
 
 /* Several devices from one host thread.  The reference's host is a single Unity process

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -132,7 +133,46 @@ __global__ __launch_bounds__(256) void add_image_kernel(float4 *dst, const float
 }
 }  // namespace ptrace
 
+// ---- pt_trace_rays_static: every device buffer of a ray query in one array that exists from load time on
+//   [0, kStaticIds)            origins + directions, 6 floats per ray (staging of the caller's host buffer)
+//   [kStaticIds, kStaticT)     hit ids                      [kStaticT, kStaticStack)   hit distances
+//   [kStaticStack, end)        traversal-stack overflow, [entry][thread] over the launch's threads
+// Each GPU holds its own copy at its own address; calls on one GPU share it, so calls that overlap there race.
+constexpr size_t kStaticMaxRays = PT_TRACE_RAYS_STATIC_MAX;
+constexpr size_t kStaticIds = kStaticMaxRays * 6 * sizeof(float);
+constexpr size_t kStaticT = kStaticIds + kStaticMaxRays * sizeof(int32_t);
+constexpr size_t kStaticStack = kStaticT + kStaticMaxRays * sizeof(float);
+constexpr size_t kStaticBytes = kStaticStack + kStaticMaxRays * (size_t)kStackOverflow * sizeof(uint32_t);
+static_assert(kStaticMaxRays % kBlock == 0 && kStaticIds % 256 == 0 && kStaticT % 256 == 0 && kStaticStack % 256 == 0, "scratch layout");
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
 namespace {
+
+// The array's address on each device (hipGetSymbolAddress with that device current), looked up by the first
+// pt_create on the device.  Host code uses these pointers only, never the array's name.
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxScratchDevices] = {};
+
+// Call with `device` current.
+hipError_t resolve_scratch(int device)
+{
+    if (device < 0 || device >= kMaxScratchDevices) return hipSuccess;     // pt_trace_rays_static reports it when asked
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    return hipSuccess;
+}
+
+unsigned char *scratch_of(int device)
+{
+    if (device < 0 || device >= kMaxScratchDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[device];
+}
 
 thread_local std::string g_create_error;
 
@@ -580,6 +620,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
         return PT_ERR_HIP;
     };
     if (!g.ok) return bail("hipSetDevice", hipErrorInvalidDevice);
+    if ((e = resolve_scratch(device_ordinal)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1260,6 +1301,42 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
         return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
     }
     cleanup();
+    return PT_OK;
+}
+
+int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays, int brute_force, int32_t *ids_out, float *t_out)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (n_rays < 0 || (n_rays > 0 && (!origins_dirs || !ids_out || !t_out)))
+        return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: bad arguments");
+    if ((size_t)n_rays > kStaticMaxRays)
+        return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: at most " + std::to_string(kStaticMaxRays) + " rays per call (PT_TRACE_RAYS_STATIC_MAX)");
+    if (n_rays == 0) return PT_OK;
+    // Building or re-inflating the scene allocates; this call does not, so the scene must be ready.
+    if (ctx->scene_dirty || (tree_width(ctx) == 2 && ctx->bvh2_stale))
+        return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: the scene has changed since it was last built; call pt_render or pt_trace_rays once first");
+    if (!ctx->spheres.empty() && reach_needed(ctx, origins_dirs, n_rays, 6) > ctx->sphere_reach)
+        return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: a ray starts farther from the scene than its tree was built for; call pt_trace_rays once with such rays first");
+    unsigned char *base = scratch_of(ctx->device);
+    if (!base) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_trace_rays_static: no scratch array on this device (ordinal beyond " + std::to_string(kMaxScratchDevices - 1) + ")");
+    DeviceGuard g(ctx->device);
+    float *d_od = reinterpret_cast<float *>(base);
+    int32_t *d_id = reinterpret_cast<int32_t *>(base + kStaticIds);
+    float *d_t = reinterpret_cast<float *>(base + kStaticT);
+    uint32_t *d_stack = reinterpret_cast<uint32_t *>(base + kStaticStack);
+    const int grid = (n_rays + kBlock - 1) / kBlock;      // grid * kBlock <= kStaticMaxRays threads, kStackOverflow entries each
+    PT_HIP(ctx, hipMemcpyAsync(d_od, origins_dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice, ctx->stream));
+    const SceneDev sc = scene_dev(ctx);
+    if (brute_force)
+        hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
+    else if (tree_width(ctx) == 4)
+        hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_stack, d_od, n_rays, d_id, d_t);
+    else
+        hipLaunchKernelGGL(trace_rays_bvh_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_stack, d_od, n_rays, d_id, d_t);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(ids_out, d_id, (size_t)n_rays * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(t_out, d_t, (size_t)n_rays * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 

@@ -165,6 +165,14 @@ class PathTracer:
                                             ids.ctypes.data, ts.ctypes.data), "pt_trace_rays")
         return ids, ts
 
+    def trace_rays_static(self, origins_dirs, brute_force=False):
+        """pt_trace_rays_static: the same query without any device allocation (at most PT_TRACE_RAYS_STATIC_MAX rays)."""
+        od = np.ascontiguousarray(origins_dirs, np.float32).reshape(-1, 6)
+        ids = np.empty(len(od), np.int32); ts = np.empty(len(od), np.float32)
+        self._check(self._lib.pt_trace_rays_static(self._ctx, od.ctypes.data, len(od), int(bool(brute_force)),
+                                                   ids.ctypes.data, ts.ctypes.data), "pt_trace_rays_static")
+        return ids, ts
+
 
 class PathTracerGroup:
     """pt_group_*: one context per listed device, driven from this thread; `members[i]` is a PathTracer."""
