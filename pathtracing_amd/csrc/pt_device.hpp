@@ -101,6 +101,14 @@ struct RenderArgs {
     float alpha_origin[3];        // renderMode 7 / 8: origin of the CURRENT camera, which the alpha channel measures from (SH:940-941)
     const float *skip_t;          // renderMode 8: t of every pixel's current primary hit; pixels with a miss are not traced (SH:760-763)
     int32_t copy_all;             // renderMode 7 / 8, first dispatch of a cycle: the pixel also goes to Result1 and Result (SH:944-947)
+    // expensive blocks first (both path kernels)
+    const uint32_t *block_order;  // NULL, or the 8x8 pixel blocks of the tile rectangle by falling cost of the previous frame
+    uint32_t *block_cost;         // NULL, or one counter per block: path length of every pixel's first sample, for the next frame's order
+    uint32_t n_blocks;            // blocks in the tile rectangle
+    // path_pool_kernel (pt_pool.hpp)
+    float4 *pool_state;           // 3 x float4 per slot of the grid: what only Shade() touches
+    int32_t pool_vote_shade, pool_vote_node, pool_vote_leaf;   // how many slots each phase wants to see before it is worth running
+    int32_t pool_cont;            // the node phase keeps stepping while at least pool_cont / 64 of the gathered rays hold an inner node
 };
 
 constexpr int kBlock = 256;            // 4 waves
@@ -125,23 +133,29 @@ __device__ __forceinline__ f3 xyz(float4 q) { return pt_make3(q.x, q.y, q.z); }
 // thread t at lds[e * kBlock + t]: consecutive lanes hit consecutive banks), deeper
 // entries in a global overflow buffer laid out [entry][global thread] so that a
 // wave's accesses coalesce.  bvh.hpp's kMaxDepth bounds the total.
-struct Stack {
-    uint32_t *lds;        // &lds_stack[threadIdx.x]
-    uint32_t *overflow;   // &overflow[global thread id]
-    uint32_t stride;      // threads in the grid
+template <int LDS_ENTRIES, int LDS_STRIDE>
+struct StackT {
+    uint32_t *lds;        // entry 0 of this lane's stack; entry e lies LDS_STRIDE words further per entry
+    uint32_t *overflow;   // entry LDS_ENTRIES of this lane's stack in the global buffer
+    uint32_t stride;      // words between consecutive overflow entries (stacks in the grid)
+    static constexpr int kLds = LDS_ENTRIES, kStride = LDS_STRIDE;
+    static constexpr int kCapacity = kStackLds + kStackOverflow;
 };
+typedef StackT<kStackLds, kBlock> Stack;   // one stack per thread of a kBlock-thread block: &lds_stack[threadIdx.x], &overflow[global thread id]
 
-__device__ __forceinline__ void stack_push(const Stack &s, int &sp, int32_t v)
+template <class ST>
+__device__ __forceinline__ void stack_push(const ST &s, int &sp, int32_t v)
 {
-    if (sp < kStackLds) s.lds[sp * kBlock] = (uint32_t)v;
-    else if (sp < kStackLds + kStackOverflow) s.overflow[(size_t)(sp - kStackLds) * s.stride] = (uint32_t)v;
+    if (sp < ST::kLds) s.lds[sp * ST::kStride] = (uint32_t)v;
+    else if (sp < ST::kCapacity) s.overflow[(size_t)(sp - ST::kLds) * s.stride] = (uint32_t)v;
     sp++;  // beyond capacity the entry would be dropped; the host never launches on a tree that can get there
 }
-__device__ __forceinline__ int32_t stack_pop(const Stack &s, int &sp)
+template <class ST>
+__device__ __forceinline__ int32_t stack_pop(const ST &s, int &sp)
 {
     sp--;
-    if (sp < kStackLds) return (int32_t)s.lds[sp * kBlock];
-    if (sp < kStackLds + kStackOverflow) return (int32_t)s.overflow[(size_t)(sp - kStackLds) * s.stride];
+    if (sp < ST::kLds) return (int32_t)s.lds[sp * ST::kStride];
+    if (sp < ST::kCapacity) return (int32_t)s.overflow[(size_t)(sp - ST::kLds) * s.stride];
     return 0;
 }
 
@@ -207,13 +221,9 @@ __device__ __forceinline__ RaySlabs ray_slabs(f3 o, f3 d)
 // One inner node: test the children, push the ones to visit later (farther ones deeper), return
 // the nearest one entered - or the next stacked node, or kDoneNode.  The slab tests use a widened
 // exit distance and non-strict comparisons: they may enter a box needlessly, never skip one.
-template <int WIDE>
-__device__ __forceinline__ int32_t node_step(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
-                                             const Stack &st, int &sp);
-
-template <>
-__device__ __forceinline__ int32_t node_step<2>(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
-                                                const Stack &st, int &sp)
+template <class ST>
+__device__ __forceinline__ int32_t node_step2(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
+                                              const ST &st, int &sp)
 {
     const float4 *q = sc.nodes + (size_t)node * 4;
     float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -242,9 +252,9 @@ __device__ __forceinline__ int32_t node_step<2>(const SceneDev &sc, int32_t node
 
 __device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 
-template <>
-__device__ __forceinline__ int32_t node_step<4>(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
-                                                const Stack &st, int &sp)
+template <class ST>
+__device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
+                                              const ST &st, int &sp)
 {
     const uint4 *q = sc.nodes4 + (size_t)node * 4;
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
@@ -285,13 +295,13 @@ __device__ __forceinline__ int32_t node_step<4>(const SceneDev &sc, int32_t node
     const int32_t c0 = child_of(key[0]), c1 = child_of(key[1]), c2 = child_of(key[2]), c3 = child_of(key[3]);
     // children to stack: keys 1 .. hits-1, farthest first so that the nearest of them is popped first
     const int np = key[3] != 0xffffffffu ? 3 : key[2] != 0xffffffffu ? 2 : key[1] != 0xffffffffu ? 1 : 0;
-    if (sp + 3 <= kStackLds) {
+    if (sp + 3 <= ST::kLds) {
         // room for three in LDS: store three unconditionally (entries past np are never read), advance by np
         const int32_t e0 = np == 3 ? c3 : np == 2 ? c2 : c1;
         const int32_t e1 = np == 3 ? c2 : c1;
-        st.lds[sp * kBlock] = (uint32_t)e0;
-        st.lds[(sp + 1) * kBlock] = (uint32_t)e1;
-        st.lds[(sp + 2) * kBlock] = (uint32_t)c1;
+        st.lds[sp * ST::kStride] = (uint32_t)e0;
+        st.lds[(sp + 1) * ST::kStride] = (uint32_t)e1;
+        st.lds[(sp + 2) * ST::kStride] = (uint32_t)c1;
         sp += np;
     } else {
         if (np == 3) stack_push(st, sp, c3);
@@ -302,9 +312,18 @@ __device__ __forceinline__ int32_t node_step<4>(const SceneDev &sc, int32_t node
     return c0;
 }
 
+template <int WIDE, class ST>
+__device__ __forceinline__ int32_t node_step(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
+                                             const ST &st, int &sp)
+{
+    if constexpr (WIDE == 2) return node_step2(sc, node, r, tbest, st, sp);
+    else return node_step4(sc, node, r, tbest, st, sp);
+}
+
 // One leaf: every primitive of it against the ray, then the next stacked node (or kDoneNode).
+template <class ST>
 __device__ __forceinline__ int32_t leaf_step(const SceneDev &sc, int32_t node, f3 o, f3 d, float &tbest, int32_t &idbest,
-                                             uint32_t &recbest, const Stack &st, int &sp, uint32_t &n_prims)
+                                             uint32_t &recbest, const ST &st, int &sp, uint32_t &n_prims)
 {
     uint32_t enc = (uint32_t)~node;
     uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
@@ -324,9 +343,9 @@ __device__ __forceinline__ int32_t leaf_step(const SceneDev &sc, int32_t node, f
 
 // Closest hit over spheres and triangles through the BVH.  tbest/idbest come in
 // holding the ground-plane result (or +inf / -1).
-template <int WIDE>
+template <int WIDE, class ST>
 __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &tbest, int32_t &idbest,
-                                         uint32_t &recbest, const Stack &st, uint32_t &n_nodes, uint32_t &n_prims)
+                                         uint32_t &recbest, const ST &st, uint32_t &n_nodes, uint32_t &n_prims)
 {
     if (sc.n_nodes == 0) return;
     const RaySlabs r = ray_slabs(o, d);
@@ -561,13 +580,30 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, int px, int py, 
 
 // Work item i -> 8x8 pixel block i/64 of the tile rectangle (row-major blocks), pixel i%64 inside
 // it, so 64 consecutive items are one block.  Returns false for items outside the rectangle.
+// With a block order the item's block is looked up instead: the frame's work counters each hand out a contiguous range
+// of items, and counter s takes the blocks of rank s, s + n, s + 2n, ... (n counters), so that every counter - and with
+// them the frame as a whole - goes from the most expensive blocks to the cheapest: the pixels still in flight when the
+// counters run dry are then cheap ones, which shortens the tail of a persistent dispatch.
 __device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, int &x, int &y)
 {
     uint32_t blk = item >> 6, in = item & 63u;
+    if (a.block_order) {
+        const uint32_t shard_blocks = a.shard_items >> 6;
+        const uint32_t rank = (blk % shard_blocks) * (uint32_t)a.n_shards + blk / shard_blocks;
+        if (rank >= a.n_blocks) { x = y = 0; return false; }
+        blk = a.block_order[rank];
+    }
     int bx = (int)(blk % (uint32_t)a.tiles_x), by = (int)(blk / (uint32_t)a.tiles_x);
     x = a.tx0 + bx * 8 + (int)(in & 7u);
     y = a.ty0 + by * 8 + (int)(in >> 3);
     return x < a.tx0 + a.tw && y < a.ty0 + a.th;
+}
+
+// The length of a pixel's first path goes to its block's cost counter.
+__device__ __forceinline__ void note_cost(const RenderArgs &a, int pix_x, int pix_y, int path_length)
+{
+    if (a.block_cost)
+        atomicAdd(a.block_cost + (uint32_t)((pix_y - a.ty0) >> 3) * (uint32_t)a.tiles_x + (uint32_t)((pix_x - a.tx0) >> 3), (uint32_t)path_length);
 }
 
 // dot(_Pixel, float2(12.9898, 78.233)) with _Pixel = id.xy * 2 (SH:831, SH:52)
@@ -910,6 +946,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     bounce++;
                     new_ray = true;
                     if (path_done) {
+                        if (sample == 0) note_cost(a, pix_x, pix_y, bounce);
                         sample++;
                         if (sample < a.spp) {                          // next sample of the same pixel, SH:839
                             bounce = 0;
@@ -1084,6 +1121,27 @@ template <int WIDE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void path_sched_mat_kernel(const RenderArgs a)
 {
     path_sched_body<WIDE, true>(a);
+}
+
+// order[] = the blocks by falling cost (a counting sort on the clamped cost; ties in no particular order: any
+// permutation renders the same image), and the counters back to zero for the frame that is about to start.
+constexpr int kOrderThreads = 1024, kOrderBins = 2048;
+__global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *cost, uint32_t *order, uint32_t n_blocks)
+{
+    __shared__ uint32_t bin[kOrderBins];
+    for (int i = threadIdx.x; i < kOrderBins; i += kOrderThreads) bin[i] = 0;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) atomicAdd(&bin[min(cost[b], (uint32_t)kOrderBins - 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {                 // first rank of every bin, most expensive bin first
+        uint32_t run = 0;
+        for (int i = kOrderBins - 1; i >= 0; i--) { const uint32_t c = bin[i]; bin[i] = run; run += c; }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) {
+        order[atomicAdd(&bin[min(cost[b], (uint32_t)kOrderBins - 1u)], 1u)] = b;
+        cost[b] = 0;
+    }
 }
 
 template <int WIDE>

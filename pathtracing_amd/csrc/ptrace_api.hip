@@ -17,6 +17,7 @@
 #include "bvh.hpp"
 #include "pt_device.hpp"
 #include "pt_wavefront.hpp"
+#include "pt_pool.hpp"
 #include "pt_screen.hpp"
 #include "pt_refit.hpp"
 
@@ -101,7 +102,17 @@ struct pt_context {
     int sched_blocks_per_cu = 0, sched_ext_blocks_per_cu = 0;   // resident blocks per CU of path_sched_kernel / path_sched_mat_kernel
     int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
     int reuse_primary = 0;                 // option "reuse_primary_hit"
-    int backend = 0;                       // 0 = path_kernel (one persistent kernel), 1 = wavefront stages
+    int backend = 0;                       // 0 = path_sched_kernel (one ray per lane), 1 = wavefront stages, 2 = path_pool_kernel (ray pool per wave)
+    int pool_blocks_per_cu = 0, pool_ext_blocks_per_cu = 0;   // resident one-wave blocks per CU of path_pool_kernel / path_pool_mat_kernel
+    int pool_vote_shade = 56, pool_vote_node = 56, pool_vote_leaf = 32, pool_cont = 48;
+    float4 *d_pool_state = nullptr;        // 3 float4 per slot
+    size_t pool_slots = 0;
+    // expensive blocks first: the cost of every 8x8 pixel block as the last dispatch over the same rectangle measured it
+    int block_order = 1;                   // option "block_order"
+    uint32_t *d_block_cost = nullptr, *d_block_order = nullptr;
+    size_t order_capacity = 0;             // blocks the two arrays hold
+    bool order_ready = false;              // d_block_order is a permutation for order_key
+    int order_key[6] = {0, 0, 0, 0, 0, 0}; // W, H, x0, y0, tw, th of the dispatch that produced the costs
     int trace_blocks_per_cu = 0, shade_blocks_per_cu = 0;
     float4 *wf_state = nullptr;            // 5 float4 arrays of wf_slots entries
     uint32_t *wf_queues = nullptr;         // 2 queues of wf_slots entries
@@ -496,7 +507,7 @@ int validate_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects,
     return PT_OK;
 }
 
-// The traversal stack's overflow area for a launch of `threads` threads.
+// The traversal stack's overflow area for a launch of `threads` threads with kStackOverflow entries each.
 int ensure_stack_overflow(pt_context *ctx, size_t threads)
 {
     if (threads <= ctx->stack_ovf_threads) return PT_OK;
@@ -640,16 +651,29 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->sched_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_mat_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched_ext_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->pool_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_mat_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->pool_ext_blocks_per_cu = std::max(1, bpc);
     if (const char *env = std::getenv("PTRACE_BACKEND")) {
         if (std::strcmp(env, "sched") == 0 || std::strcmp(env, "mega") == 0) ctx->backend = 0;
         else if (std::strcmp(env, "wavefront") == 0 || std::strcmp(env, "wave") == 0) ctx->backend = 1;
-        else std::fprintf(stderr, "libptrace: PTRACE_BACKEND=%s ignored (sched | wavefront)\n", env);
+        else if (std::strcmp(env, "pool") == 0) ctx->backend = 2;
+        else std::fprintf(stderr, "libptrace: PTRACE_BACKEND=%s ignored (sched | wavefront | pool)\n", env);
     }
     if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : 4;
+    if (const char *env = std::getenv("PTRACE_BLOCK_ORDER")) ctx->block_order = std::atoi(env) != 0;
     if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_NODE")) ctx->vote_node = std::max(1, std::min(64, std::atoi(env)));
+    if (const char *env = std::getenv("PTRACE_POOL_VOTES")) {     // shade,node,leaf,cont
+        int v[4] = {ctx->pool_vote_shade, ctx->pool_vote_node, ctx->pool_vote_leaf, ctx->pool_cont};
+        if (std::sscanf(env, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 1) {
+            for (int &x : v) x = std::max(1, std::min(64, x));
+            ctx->pool_vote_shade = v[0]; ctx->pool_vote_node = v[1]; ctx->pool_vote_leaf = v[2]; ctx->pool_cont = v[3];
+        }
+    }
     if (const char *env = std::getenv("PTRACE_VOTE")) ctx->node_vote = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_REFILL")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(env)));
     *out_ctx = ctx;
@@ -675,7 +699,8 @@ void pt_destroy(pt_context *ctx)
         if (ctx->ev_cams[i]) (void)hipEventDestroy(ctx->ev_cams[i]);
     }
     if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
-    free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters);
+    free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters); free_dev(ctx->d_pool_state);
+    free_dev(ctx->d_block_cost); free_dev(ctx->d_block_order);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -830,6 +855,7 @@ int pt_resize(pt_context *ctx, int width, int height)
     if (rebind_i) ctx->ids = nullptr;
     if (rebind_2) ctx->result2 = nullptr;
     ctx->W = ctx->H = 0;
+    ctx->order_ready = false;
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     if (ctx->display == ctx->own_display) ctx->display = nullptr;
@@ -893,6 +919,70 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         a.n_shards = std::max(1, std::min(kWorkShards, shards));
         a.shard_items = ((blocks + a.n_shards - 1) / a.n_shards) * 64u;
     }
+    // ---- expensive blocks first.  Worth it when a pixel is long (many samples x bounces): then the dispatch ends with
+    // every lane inside its last pixel, and it matters which pixels those are.  The costs come from the previous dispatch
+    // over the same rectangle; the order kernel after this launch prepares the next one's.
+    a.block_order = nullptr; a.block_cost = nullptr; a.n_blocks = a.total_items / 64u;
+    const bool want_order = ctx->block_order && a.n_blocks >= 1024 && (int64_t)a.spp * a.maxb >= 32;
+    const int key[6] = {ctx->W, ctx->H, x0, y0, tw, th};
+    if (want_order) {
+        if (a.n_blocks > ctx->order_capacity) {
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            free_dev(ctx->d_block_cost); free_dev(ctx->d_block_order); ctx->order_capacity = 0; ctx->order_ready = false;
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_block_cost, a.n_blocks * sizeof(uint32_t)));
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_block_order, a.n_blocks * sizeof(uint32_t)));
+            ctx->order_capacity = a.n_blocks;
+        }
+        if (!ctx->order_ready || std::memcmp(key, ctx->order_key, sizeof key) != 0) {
+            ctx->order_ready = false;
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_block_cost, 0, a.n_blocks * sizeof(uint32_t), ctx->stream));
+        } else {
+            a.block_order = ctx->d_block_order;
+            a.total_items = (uint32_t)a.n_shards * a.shard_items;     // every counter hands out whole ranks; ranks past the last block are skipped
+        }
+        a.block_cost = ctx->d_block_cost;
+    }
+    struct AfterLaunch {                    // queue the order kernel behind whichever path kernel is launched below
+        pt_context *ctx; const RenderArgs &a; bool want; const int *key;
+        int done() const
+        {
+            if (!want) return PT_OK;
+            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(kOrderThreads), 0, ctx->stream, ctx->d_block_cost, ctx->d_block_order, a.n_blocks);
+            if (hipGetLastError() != hipSuccess) return PT_ERR_HIP;
+            std::memcpy(ctx->order_key, key, sizeof ctx->order_key);
+            ctx->order_ready = true;
+            return PT_OK;
+        }
+    } after{ctx, a, want_order, key};
+    if (ctx->backend == 2) {
+        // one wave per block, kPoolK * 64 ray slots per wave
+        constexpr int P = 64 * kPoolK;
+        const int fit = extended ? ctx->pool_ext_blocks_per_cu : ctx->pool_blocks_per_cu;
+        int per_cu = fit;
+        if (ctx->blocks_per_cu > 0) per_cu = std::max(1, fit * std::min(ctx->blocks_per_cu, ctx->sched_blocks_per_cu) / ctx->sched_blocks_per_cu);
+        const int grid = (int)std::min<int64_t>(((int64_t)a.total_items + 63) / 64, (int64_t)ctx->num_cus * per_cu);
+        const size_t slots = (size_t)grid * P;
+        // overflow entries: what a slot's stack may hold beyond the kPoolSE entries in LDS
+        const size_t ovf_entries = slots * (size_t)(kStackLds + kStackOverflow - kPoolSE);
+        if ((rc = ensure_stack_overflow(ctx, (ovf_entries + kStackOverflow - 1) / kStackOverflow))) return rc;
+        if (slots > ctx->pool_slots) {
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            free_dev(ctx->d_pool_state); ctx->pool_slots = 0;
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_pool_state, slots * 3 * sizeof(float4)));
+            ctx->pool_slots = slots;
+        }
+        a.stack_overflow = ctx->d_stack_ovf; a.pool_state = ctx->d_pool_state;
+        a.pool_vote_shade = ctx->pool_vote_shade; a.pool_vote_node = ctx->pool_vote_node; a.pool_vote_leaf = ctx->pool_vote_leaf; a.pool_cont = ctx->pool_cont;
+        if (extended) {
+            if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_pool_mat_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(path_pool_mat_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        } else {
+            if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_pool_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(path_pool_kernel<2>, dim3(grid), dim3(64), 0, ctx->stream, a);
+        }
+        PT_HIP(ctx, hipGetLastError());
+        return after.done();
+    }
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
     const int fit = extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
     const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, fit) : fit;
@@ -908,7 +998,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     }
     PT_HIP(ctx, hipGetLastError());
-    return PT_OK;
+    return after.done();
 }
 
 // Primary rays only over the rectangle: what == 1 the _Depth dispatch, what == 2 t of the hits into d_seeds.
@@ -1026,6 +1116,7 @@ static int render_frame(pt_context *ctx, const PtFrameParams *p)
     std::memcpy(a.old_w2c, ctx->camera_history[0].world_to_camera, sizeof a.old_w2c);
     std::memcpy(a.old_proj, ctx->camera_history[0].camera_projection, sizeof a.old_proj);
     a.result2 = ctx->result2; a.seed_out = ctx->d_seeds;
+    a.block_order = nullptr; a.block_cost = nullptr; a.n_blocks = 0; a.pool_state = nullptr;
 
     if (!ctx->epoch_open) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, kStatsShards * kStatsStride * sizeof(unsigned long long), ctx->stream));
@@ -1134,13 +1225,18 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
     if (!ctx) return PT_ERR_INVALID;
     if (!name) return fail(ctx, PT_ERR_INVALID, "pt_set_option: name is NULL");
     if (std::strcmp(name, "backend") == 0) {
-        if (value < 0 || value > 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: backend must be 0 or 1");
+        if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: backend must be 0, 1 or 2");
         ctx->backend = value;
         return PT_OK;
     }
     if (std::strcmp(name, "bvh_width") == 0) {
         if (value != 2 && value != 4) return fail(ctx, PT_ERR_INVALID, "pt_set_option: bvh_width must be 2 or 4");
         ctx->bvh_width = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "block_order") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: block_order must be 0 or 1");
+        ctx->block_order = value; ctx->order_ready = false;
         return PT_OK;
     }
     if (std::strcmp(name, "reuse_primary_hit") == 0) {

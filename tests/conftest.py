@@ -18,14 +18,15 @@ def sky_small():
     return pa.procedural_sky(128, 64)
 
 
-@pytest.fixture(scope="session", params=["sched-bvh4", "sched-bvh2", "wavefront-bvh4"])
+@pytest.fixture(scope="session", params=["sched-bvh4", "sched-bvh2", "wavefront-bvh4", "pool-bvh4", "pool-bvh2"])
 def tracer(request):
     """One libptrace context on cuda:0 per implementation variant: the scheduled persistent kernel
-    (default) over the four-wide and the binary BVH, and the wavefront stages.  All must match the oracle."""
+    (default) over the four-wide and the binary BVH, the wavefront stages, and the kernel with a ray pool per wave.  All
+    must match the oracle."""
     import pathtracing_amd as pa
     t = pa.PathTracer(0)
     backend, width = request.param.split("-bvh")
-    t.set_option("backend", {"sched": 0, "wavefront": 1}[backend])
+    t.set_option("backend", {"sched": 0, "wavefront": 1, "pool": 2}[backend])
     t.set_option("bvh_width", int(width))
     yield t
     t.close()

@@ -1203,3 +1203,32 @@ def test_many_samples_and_long_paths_in_one_dispatch(tracer, fixture_scene, sky_
     for bad in (dict(spp=1 << 20), dict(max_bounces=4096)):
         with pytest.raises(pa.PtraceError):
             tracer.render(pa.make_params(s, W, H, **bad))
+
+
+def test_expensive_blocks_first_renders_the_same_image(tracer, sky_small):
+    """From the second dispatch over the same rectangle on, the path kernels hand out the 8x8 pixel blocks by falling cost
+    of the previous dispatch (the tail of a persistent dispatch then consists of cheap pixels).  Any order must give the
+    same image, hit ids and ray count: an odd size (the last work counter gets fewer blocks), a sub-rectangle, and the
+    order switched off."""
+    s = pa.Scene("fixture")
+    tracer.load_scene(s, sky_small)
+    tracer.set_mesh_materials(None)
+    orc = po.Oracle.from_scene(s, sky_small, accel=True)
+    W, H = 397, 283
+    tracer.resize(W, H)
+    for tile in (None, (13, 9, 371, 270)):
+        p = pa.make_params(s, W, H, seed=0.25, spp=4, max_bounces=8, tile=tile)
+        want, want_ids, wst = orc.render(p, W, H, threads=8)
+        for k in range(3):                       # the first dispatch measures, the later ones use the order
+            tracer.set_option("block_order", 0 if k == 2 else 1)
+            tracer.write_target(pa.PT_TARGET_RESULT, np.zeros((H, W, 4), np.float32))
+            tracer.stats(); tracer.render(p)
+            g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+            x0, y0, tw, th = tile if tile else (0, 0, W, H)
+            _assert_same_image(g[y0:y0 + th, x0:x0 + tw], want[y0:y0 + th, x0:x0 + tw], f"dispatch {k}, tile {tile}")
+            assert (gid[y0:y0 + th, x0:x0 + tw] == want_ids[y0:y0 + th, x0:x0 + tw]).all()
+            assert st["rays"] == wst["rays"] and st["paths"] == wst["paths"]
+            if tile:
+                outside = np.ones((H, W), bool); outside[y0:y0 + th, x0:x0 + tw] = False
+                assert (g[outside] == 0).all()
+    tracer.set_option("block_order", 1)
