@@ -1029,23 +1029,38 @@ static void node_bounds(PtoPrepared *p, const int32_t *ids, int32_t n, float *lo
     }
 }
 
-static int g_axis; static PtoPrepared *g_p;
-static float centroid(int32_t id, int axis)
+static float centroid(const PtoPrepared *p, int32_t id, int axis)
 {
-    if (id <= g_p->n_spheres) return g_p->spheres[id - 1].position[axis];
-    const Tri *t = &g_p->tris[id - 1 - g_p->n_spheres];
+    if (id <= p->n_spheres) return p->spheres[id - 1].position[axis];
+    const Tri *t = &p->tris[id - 1 - p->n_spheres];
     const float *a = &t->v0.x, *b = &t->v1.x, *c = &t->v2.x;
     return 0.5f * (fminf(a[axis], fminf(b[axis], c[axis])) + fmaxf(a[axis], fmaxf(b[axis], c[axis])));
 }
-static int cmp_centroid(const void *x, const void *y)
+
+/* Rearranges ids[0..n) so that ids[k] is the element a sort by key[id - 1] would put there, smaller keys before it and
+ * larger ones after it (quickselect, median-of-three pivot).  Which primitives share a leaf does not matter to the
+ * results: the closest hit is the (distance, id)-smallest one whatever the tree looks like. */
+static void select_kth(int32_t *ids, int32_t n, int32_t k, const float *key)
 {
-    float a = centroid(*(const int32_t *)x, g_axis), b = centroid(*(const int32_t *)y, g_axis);
-    return (a > b) - (a < b);
+    int32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        const float x = key[ids[lo] - 1], y = key[ids[mid] - 1], z = key[ids[hi] - 1];
+        const float pv = x < y ? (y < z ? y : (x < z ? z : x)) : (x < z ? x : (y < z ? z : y));
+        int32_t i = lo, j = hi;
+        while (i <= j) {
+            while (key[ids[i] - 1] < pv) i++;
+            while (key[ids[j] - 1] > pv) j--;
+            if (i <= j) { const int32_t t = ids[i]; ids[i] = ids[j]; ids[j] = t; i++; j--; }
+        }
+        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
+    }
 }
 
-static int32_t build_node(PtoPrepared *p, int32_t first, int32_t n, float pad)
+/* cent: the primitives' box centres, [axis][id - 1].  Large subtrees are built as OpenMP tasks. */
+static int32_t build_node(PtoPrepared *p, int32_t first, int32_t n, float pad, const float *cent, int32_t np)
 {
-    int32_t me = p->n_nodes++;
+    int32_t me = __atomic_fetch_add(&p->n_nodes, 1, __ATOMIC_RELAXED);
     float lo[3], hi[3], clo[3], chi[3];
     node_bounds(p, p->order + first, n, lo, hi, clo, chi);
     ONode *nd = &p->nodes[me];
@@ -1055,11 +1070,18 @@ static int32_t build_node(PtoPrepared *p, int32_t first, int32_t n, float pad)
     if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
     if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
     if (n <= 4 || !(chi[axis] > clo[axis])) { nd->count = n; return me; }
-    g_axis = axis; g_p = p;
-    qsort(p->order + first, (size_t)n, sizeof(int32_t), cmp_centroid);
     int32_t half = n / 2;
-    int32_t l = build_node(p, first, half, pad);
-    int32_t r = build_node(p, first + half, n - half, pad);
+    select_kth(p->order + first, n, half, cent + (size_t)axis * (size_t)np);
+    int32_t l = -1, r = -1;
+    if (n > 65536) {
+#pragma omp task shared(l) firstprivate(p, first, half, pad, cent, np)
+        l = build_node(p, first, half, pad, cent, np);
+        r = build_node(p, first + half, n - half, pad, cent, np);
+#pragma omp taskwait
+    } else {
+        l = build_node(p, first, half, pad, cent, np);
+        r = build_node(p, first + half, n - half, pad, cent, np);
+    }
     p->nodes[me].left = l; p->nodes[me].right = r;
     return me;
 }
@@ -1113,7 +1135,13 @@ PtoPrepared *pto_prepare(const PtoScene *sc, int accel)
         float lo[3], hi[3], clo[3], chi[3];
         node_bounds(p, p->order, np, lo, hi, clo, chi);
         float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-        build_node(p, 0, np, 1e-5f * diag + 1e-6f);
+        float *cent = (float *)malloc(sizeof(float) * 3 * (size_t)np);
+        for (int axis = 0; axis < 3; axis++)
+            for (int32_t i = 0; i < np; i++) cent[(size_t)axis * (size_t)np + i] = centroid(p, i + 1, axis);
+#pragma omp parallel
+#pragma omp single
+        build_node(p, 0, np, 1e-5f * diag + 1e-6f, cent, np);
+        free(cent);
     }
     return p;
 }
