@@ -100,6 +100,15 @@ PTMASTER_SYMBOLS = {
     "ptm_camera_history_entry": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                         _P(PtCameraHistory)]),
     "ptm_frame_seed": (C.c_float, [C.c_uint32]),
+    "ptm_matrix_inverse": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptm_camera_stereo_eye": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_void_p, C.c_void_p]),
+    "ptm_master_register_object": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "ptm_master_register_instance": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ptm_master_unregister_object": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptm_master_update_object": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ptm_master_object_count": (C.c_int, [C.c_void_p]),
+    "ptm_master_set_stereo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ptm_scene_create": (C.c_void_p, [C.c_char_p]),
     "ptm_scene_destroy": (None, [C.c_void_p]),
     "ptm_scene_counts": (None, [C.c_void_p, C.c_void_p]),

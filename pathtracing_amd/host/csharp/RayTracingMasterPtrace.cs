@@ -56,7 +56,13 @@ public class RayTracingMasterPtrace : MonoBehaviour
     static readonly List<MeshObject> _meshObjects = new List<MeshObject>();
     static readonly List<Vector3> _vertices = new List<Vector3>();
     static readonly List<int> _indices = new List<int>();
-    static bool _meshObjectsNeedRebuilding;
+    static bool _meshObjectsNeedRebuilding, _objectListChanged;
+    static readonly List<RayTracingObject> _rayTracingObjects = new List<RayTracingObject>();   // :47
+
+    // :296-313, called by RayTracingObject.cs:24-38 exactly as in the reference
+    public static int RegisterObject(RayTracingObject obj) { _rayTracingObjects.Add(obj); _meshObjectsNeedRebuilding = _objectListChanged = true; return _rayTracingObjects.Count - 1; }
+    public static void UpdateObject(Transform tra) { _meshObjectsNeedRebuilding = true; }
+    public static void UnregisterObject(RayTracingObject obj) { _rayTracingObjects.Remove(obj); _meshObjectsNeedRebuilding = _objectListChanged = true; }
 
     void Check(int rc, string what) { if (rc != 0) throw new InvalidOperationException(what + ": " + Marshal.PtrToStringAnsi(pt_last_error(_ctx))); }
 
@@ -91,10 +97,22 @@ public class RayTracingMasterPtrace : MonoBehaviour
         Check(pt_set_spheres(_ctx, spheres.ToArray(), spheres.Count), "pt_set_spheres");   // replaces :362-368 + :536
     }
 
-    void RebuildMeshObjectBuffers()                            // :371-413; lists are filled by RegisterObject as in the reference
+    void RebuildMeshObjectBuffers()                            // :371-413
     {
         if (!_meshObjectsNeedRebuilding) return;
         _meshObjectsNeedRebuilding = false;
+        _meshObjects.Clear();
+        if (_objectListChanged) { _vertices.Clear(); _indices.Clear(); }
+        foreach (RayTracingObject obj in _rayTracingObjects)   // :384-405
+        {
+            Mesh mesh = obj.GetComponent<MeshFilter>().sharedMesh;
+            int firstVertex = _vertices.Count, firstIndex = _indices.Count;
+            int[] indices = mesh.GetIndices(0);
+            if (_objectListChanged) { _vertices.AddRange(mesh.vertices); foreach (int i in indices) _indices.Add(i + firstVertex); }
+            else firstIndex = _meshObjects.Count == 0 ? 0 : _meshObjects[_meshObjects.Count - 1].indices_offset + _meshObjects[_meshObjects.Count - 1].indices_count;
+            _meshObjects.Add(new MeshObject { localToWorldMatrix = obj.transform.localToWorldMatrix, indices_offset = firstIndex, indices_count = indices.Length });
+        }
+        if (_objectListChanged) { _geometryUploaded = false; _objectListChanged = false; }
         if (!_geometryUploaded)
         {
             Check(pt_set_meshes(_ctx, _meshObjects.ToArray(), _meshObjects.Count, _vertices.ToArray(), _vertices.Count, _indices.ToArray(), _indices.Count), "pt_set_meshes");   // :410-412 + :537-539
@@ -109,7 +127,12 @@ public class RayTracingMasterPtrace : MonoBehaviour
         int w = Screen.width, h = Screen.height;
         if (w != _width || h != _height) { Check(pt_resize(_ctx, w, h), "pt_resize"); _width = w; _height = h; }   // :542-583
         var p = new PtFrameParams();
-        Matrix4x4 c2w = _camera.cameraToWorldMatrix, ip = _camera.projectionMatrix.inverse;                       // :489-490
+        // :459-467 / :489-490 - a stereo camera renders one eye per instance, with that eye's own view and projection
+        bool stereo = _camera.stereoEnabled, left = _camera.stereoTargetEye == StereoTargetEyeMask.Left;
+        Camera.StereoscopicEye which = left ? Camera.StereoscopicEye.Left : Camera.StereoscopicEye.Right;
+        Matrix4x4 w2c = stereo ? _camera.GetStereoViewMatrix(which) : _camera.worldToCameraMatrix;
+        Matrix4x4 prj = stereo ? _camera.GetStereoProjectionMatrix(which) : _camera.projectionMatrix;
+        Matrix4x4 c2w = stereo ? w2c.inverse : _camera.cameraToWorldMatrix, ip = prj.inverse;
         for (int i = 0; i < 16; i++) { p.camera_to_world[i] = c2w[i]; p.camera_inverse_projection[i] = ip[i]; }  // Matrix4x4[i] is column-major
         p.seed = UnityEngine.Random.value;                     // :530
         p.samples_per_pixel = renderMode < 10 ? samplesPerPixel : 1;   // :531
@@ -118,12 +141,16 @@ public class RayTracingMasterPtrace : MonoBehaviour
         p.render_mode = renderMode;                            // :735
         p.accumulation_frames = (int)sampleFrames;             // :738
         p.divisions = divisions; p.counter = counter++ % divisions;   // :736-737
-        p.left_eye = _camera.stereoTargetEye == StereoTargetEyeMask.Left ? 1 : 0;   // :460-462
+        p.left_eye = stereo && left ? 1 : 0;                   // :460-462 (uploaded by the stereo branch only)
         p.accumulate = (depth || renderMode != 1) ? 0 : 3;     // AddMat.shader blend; in Reproj mode _converged is the history
-        Check(pt_set_camera_history(_ctx, _oldCameras.ToArray(), _oldCameras.Count), "pt_set_camera_history");   // :492-495
-        if (renderMode < 5 || renderMode > 8 || p.counter == 0) _oldCameras.Clear();                             // :513-518
-        if (renderMode < 11 && renderMode != 1)                                                                  // :520-526
-            _oldCameras.Add(new PtCameraHistory { cameraToWorld = c2w, cameraInverseProjection = ip, worldToCamera = _camera.worldToCameraMatrix, cameraProjection = _camera.projectionMatrix });
+        Check(pt_set_camera_history(_ctx, _oldCameras.ToArray(), _oldCameras.Count), "pt_set_camera_history");   // :468-471 / :492-495
+        // when the lists restart: the stereo branch keeps them only in modes 5 / 6 and only across the frame that starts
+        // a cycle (:473); the mono branch restarts them at the start of a cycle in modes 5 .. 8, every frame otherwise (:513)
+        bool clear = stereo ? ((renderMode != 5 && renderMode != 6) || p.counter != 0)
+                            : (renderMode < 5 || renderMode > 8 || p.counter == 0);
+        if (clear) _oldCameras.Clear();
+        if (renderMode < 11 && renderMode != 1)                                                                  // :480-485 / :520-526
+            _oldCameras.Add(new PtCameraHistory { cameraToWorld = c2w, cameraInverseProjection = ip, worldToCamera = w2c, cameraProjection = prj });
         p.sample_index = depth ? 0u : _currentSample;          // :805
         Check(pt_render(_ctx, ref p), "pt_render");            // :745-747
         if (_currentSample < sampleFrames) _currentSample++; else _currentSample = sampleFrames;   // :885-888

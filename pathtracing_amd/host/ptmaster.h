@@ -43,6 +43,15 @@ void ptm_camera_history_entry(const float eye[3], const float target[3], const f
 /* Per-frame _Seed (replaces Random.value, RayTracingMaster.cs:530): frac(0.5 + k * 0.6180339). */
 float ptm_frame_seed(uint32_t k);
 
+/* Matrix4x4.inverse (RayTracingMaster.cs:463,466,490) for a column-major 4x4; returns 0 for a singular matrix. */
+int ptm_matrix_inverse(const float m[16], float out[16]);
+
+/* One eye of a stereo camera, as Camera.GetStereoViewMatrix / GetStereoProjectionMatrix hand it to the stereo branch
+ * of SetShaderParameters (RayTracingMaster.cs:463-466): the view matrix of the look-at camera moved `offset` along its
+ * right axis, and an OpenGL projection whose frustum is sheared sideways by `shear` (an asymmetric, per-eye frustum). */
+void ptm_camera_stereo_eye(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                           float z_near, float z_far, float offset, float shear, float view[16], float proj[16]);
+
 /* ---- named synthetic scenes --------------------------------------------
  * "spheres"   Kuri part-3 field: 100 candidates, radius U(3,8), placement radius 100 (RayTracingMaster.cs:32-34)
  * "xr"        the repository's TestScene: 200 candidates, radius U(.5,3), placement 20, one rotated cube
@@ -82,6 +91,22 @@ int ptm_master_set_render_mode(ptm_master *m, int render_mode);
 int ptm_master_set_divisions(ptm_master *m, int divisions);
 /* eye_offset: signed offset along the camera's right axis (stereo: -sep/2 left, +sep/2 right). */
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov_y_deg, float eye_offset);
+/* RayTracingMaster.RegisterObject / UnregisterObject / UpdateObject (RayTracingMaster.cs:296-313), which the reference's
+ * RayTracingObject component calls from OnEnable, OnDisable and on a changed transform (RayTracingObject.cs:24-38).  A mesh
+ * is object-space vertices (xyz) and the indices of its sub-mesh 0; register returns the object's position in the list
+ * (-1 on a bad mesh), unregister moves later objects up.  register_instance adds an object sharing an earlier object's
+ * mesh.  All take effect at the next ptm_master_render(), which rebuilds the mesh buffers as :371-413 do: a full upload when
+ * the object list changed, the matrices alone when only transforms did. */
+int ptm_master_register_object(ptm_master *m, const float *vertices, int n_vertices, const int32_t *indices, int n_indices,
+                               const float local_to_world[16]);
+int ptm_master_register_instance(ptm_master *m, int of_object, const float local_to_world[16]);
+int ptm_master_unregister_object(ptm_master *m, int object);
+int ptm_master_update_object(ptm_master *m, int object, const float local_to_world[16]);
+int ptm_master_object_count(const ptm_master *m);
+/* _camera.stereoEnabled, stereoTargetEye == Left, and that eye's view and projection matrices: selects the stereo branch
+ * of SetShaderParameters (RayTracingMaster.cs:459-485) - _leftEye, inverted per-eye matrices, and its own rule for when
+ * the camera lists restart (:473).  enabled == 0 goes back to the mono branch (:486-527). */
+int ptm_master_set_stereo(ptm_master *m, int enabled, int left_eye, const float view[16], const float proj[16]);
 /* Render(): RebuildMeshObjectBuffers, SetShaderParameters, InitRenderTexture, Dispatch (RayTracingMaster.cs:704-747),
  * then the _currentSample bookkeeping of :885-888.  Asynchronous. */
 int ptm_master_render(ptm_master *m);

@@ -1,9 +1,12 @@
 // RayTracingMaster mirror + the C functions of ptmaster.h.
 #include "ray_tracing_master.hpp"
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include "ptmaster.h"
 
@@ -36,11 +39,24 @@ int RayTracingMaster::OnEnable(const Scene &scene, int sky_w, int sky_h)
     frame_ = 0;
     int rc = SetUpScene(scene);                           // :146
     if (rc) return rc;
-    // RayTracingObject.OnEnable -> RegisterObject for every mesh of the scene (:296-301)
-    meshObjects_ = scene.objects;
-    vertices_ = scene.vertices;
-    indices_ = scene.indices;
+    // RayTracingObject.OnEnable -> RegisterObject for every mesh object of the scene (:296-301).  Objects with the same
+    // index range are instances of one mesh.
+    rayTracingObjects_.clear();
+    for (size_t o = 0; o < scene.objects.size(); o++) {
+        const PtMeshObject &mo = scene.objects[o];
+        int shared = -1;
+        for (size_t q = 0; q < o && shared < 0; q++)
+            if (scene.objects[q].indices_offset == mo.indices_offset && scene.objects[q].indices_count == mo.indices_count) shared = (int)q;
+        if (shared >= 0) { RegisterInstance(shared, mo.local_to_world); continue; }
+        int32_t lo = INT32_MAX, hi = -1;
+        for (int32_t i = mo.indices_offset; i < mo.indices_offset + mo.indices_count; i++) { lo = std::min(lo, scene.indices[i]); hi = std::max(hi, scene.indices[i]); }
+        std::vector<int32_t> idx((size_t)mo.indices_count);
+        for (int32_t i = 0; i < mo.indices_count; i++) idx[(size_t)i] = scene.indices[mo.indices_offset + i] - (hi >= 0 ? lo : 0);
+        const float *v = hi >= 0 ? &scene.vertices[(size_t)lo * 3] : nullptr;
+        RegisterObject(v, hi >= 0 ? hi - lo + 1 : 0, idx.data(), (int)idx.size(), mo.local_to_world);
+    }
     meshObjectsNeedRebuilding_ = true;
+    objectListChanged_ = true;
     geometryUploaded_ = false;
     if (sky_w > 0 && sky_h > 0) {                         // SkyboxTexture (:25, :457)
         std::vector<float> sky((size_t)sky_w * sky_h * 4);
@@ -59,10 +75,45 @@ int RayTracingMaster::SetUpScene(const Scene &scene)
     return check(pt_set_spheres(ctx_, scene.spheres.data(), (int)scene.spheres.size()), "pt_set_spheres");
 }
 
+int RayTracingMaster::RegisterObject(const float *vertices, int n_vertices, const int32_t *indices, int n_indices, const float local_to_world[16])
+{
+    if (n_vertices < 0 || n_indices < 0 || (n_vertices > 0 && !vertices) || (n_indices > 0 && !indices)) { error_ = "RegisterObject: bad mesh"; return -1; }
+    for (int i = 0; i < n_indices; i++)
+        if (indices[i] < 0 || indices[i] >= n_vertices) { error_ = "RegisterObject: index outside the mesh's vertices"; return -1; }
+    auto mesh = std::make_shared<Mesh>();
+    mesh->vertices.assign(vertices, vertices + (size_t)n_vertices * 3);
+    mesh->indices.assign(indices, indices + n_indices);
+    RayTracingObject obj;
+    obj.mesh = mesh;
+    std::memcpy(obj.localToWorld, local_to_world, sizeof obj.localToWorld);
+    rayTracingObjects_.push_back(obj);                    // :298
+    meshObjectsNeedRebuilding_ = true; objectListChanged_ = true;   // :299
+    return (int)rayTracingObjects_.size() - 1;            // :300
+}
+
+int RayTracingMaster::RegisterInstance(int of_object, const float local_to_world[16])
+{
+    if (of_object < 0 || of_object >= (int)rayTracingObjects_.size()) { error_ = "RegisterInstance: no such object"; return -1; }
+    RayTracingObject obj;
+    obj.mesh = rayTracingObjects_[(size_t)of_object].mesh;
+    std::memcpy(obj.localToWorld, local_to_world, sizeof obj.localToWorld);
+    rayTracingObjects_.push_back(obj);
+    meshObjectsNeedRebuilding_ = true; objectListChanged_ = true;
+    return (int)rayTracingObjects_.size() - 1;
+}
+
+int RayTracingMaster::UnregisterObject(int object)
+{
+    if (object < 0 || object >= (int)rayTracingObjects_.size()) { error_ = "UnregisterObject: no such object"; return PT_ERR_INVALID; }
+    rayTracingObjects_.erase(rayTracingObjects_.begin() + object);   // :311
+    meshObjectsNeedRebuilding_ = true; objectListChanged_ = true;    // :312
+    return PT_OK;
+}
+
 int RayTracingMaster::UpdateObject(int object, const float local_to_world[16])
 {
-    if (object < 0 || object >= (int)meshObjects_.size()) { error_ = "UpdateObject: no such object"; return PT_ERR_INVALID; }
-    std::memcpy(meshObjects_[object].local_to_world, local_to_world, 16 * sizeof(float));
+    if (object < 0 || object >= (int)rayTracingObjects_.size()) { error_ = "UpdateObject: no such object"; return PT_ERR_INVALID; }
+    std::memcpy(rayTracingObjects_[(size_t)object].localToWorld, local_to_world, 16 * sizeof(float));
     meshObjectsNeedRebuilding_ = true;                    // :303-307
     return PT_OK;
 }
@@ -71,6 +122,33 @@ int RayTracingMaster::RebuildMeshObjectBuffers()
 {
     if (!meshObjectsNeedRebuilding_) return PT_OK;        // :373-376
     meshObjectsNeedRebuilding_ = false;
+    // :381-405 - clear the lists, then every object's vertices, its indices offset by its first vertex, and
+    // (matrix, first index, index count).  A mesh shared by several objects is appended once and referenced by all of
+    // them (the reference appends a copy per object; the triangles, their order and so the image are the same).
+    if (objectListChanged_) {
+        vertices_.clear(); indices_.clear();
+        std::vector<std::pair<const Mesh *, std::pair<int32_t, int32_t>>> placed;     // mesh -> (first index, index count)
+        meshObjects_.assign(rayTracingObjects_.size(), PtMeshObject{});
+        for (size_t o = 0; o < rayTracingObjects_.size(); o++) {
+            const Mesh *mesh = rayTracingObjects_[o].mesh.get();
+            int32_t firstIndex = -1, count = 0;
+            for (const auto &pl : placed)
+                if (pl.first == mesh) { firstIndex = pl.second.first; count = pl.second.second; }
+            if (firstIndex < 0) {
+                const int32_t firstVertex = (int32_t)(vertices_.size() / 3);               // :390
+                vertices_.insert(vertices_.end(), mesh->vertices.begin(), mesh->vertices.end());
+                firstIndex = (int32_t)indices_.size();                                      // :395
+                count = (int32_t)mesh->indices.size();
+                for (int32_t i : mesh->indices) indices_.push_back(i + firstVertex);        // :397
+                placed.push_back({mesh, {firstIndex, count}});
+            }
+            meshObjects_[o].indices_offset = firstIndex; meshObjects_[o].indices_count = count;   // :400-405
+        }
+        geometryUploaded_ = false;
+        objectListChanged_ = false;
+    }
+    for (size_t o = 0; o < rayTracingObjects_.size(); o++)
+        std::memcpy(meshObjects_[o].local_to_world, rayTracingObjects_[o].localToWorld, sizeof meshObjects_[o].local_to_world);
     int rc;
     if (!geometryUploaded_) {
         // :410-412 - all three buffers
@@ -99,11 +177,17 @@ void RayTracingMaster::currentCamera(float e[3], float t[3]) const
 void RayTracingMaster::FillParams(PtFrameParams &p) const
 {
     std::memset(&p, 0, sizeof p);
-    // _CameraToWorld / _CameraInverseProjection (:489-490; per-eye variants :463-467)
-    float e[3], t[3];
-    currentCamera(e, t);
-    float aspect = RenderHight > 0 ? (float)RenderWidth / (float)RenderHight : 1.0f;
-    camera_look_at(e, t, up, fieldOfView, aspect, nearClip, farClip, p.camera_to_world, p.camera_inverse_projection);
+    if (stereoEnabled) {
+        // :463-467 - the eye's own view and projection matrices, inverted
+        matrix_inverse(stereoView, p.camera_to_world);
+        matrix_inverse(stereoProj, p.camera_inverse_projection);
+    } else {
+        // _CameraToWorld / _CameraInverseProjection (:489-490)
+        float e[3], t[3];
+        currentCamera(e, t);
+        float aspect = RenderHight > 0 ? (float)RenderWidth / (float)RenderHight : 1.0f;
+        camera_look_at(e, t, up, fieldOfView, aspect, nearClip, farClip, p.camera_to_world, p.camera_inverse_projection);
+    }
     p.pixel_offset[0] = 0.0f; p.pixel_offset[1] = 0.0f;   // :529 (unused by the kernel)
     p.seed = frame_seed(frame_);                          // :530, deterministic stand-in for Random.value
     p.samples_per_pixel = renderMode < 10 ? samplesPerPixel : 1;   // :531
@@ -116,7 +200,9 @@ void RayTracingMaster::FillParams(PtFrameParams &p) const
     p.accumulation_frames = (int32_t)sampleFrames;        // :738
     p.divisions = divisions;                              // :736
     p.counter = divisions > 0 ? counter_ % divisions : 0; // :737 (the increment happens in Render)
-    p.left_eye = eyeOffset < 0.0f ? 1 : 0;                // :460-462 (_leftEye; read by renderMode 4 only)
+    // :460-462 - _leftEye is uploaded by the stereo branch only (read by renderMode 4); a mono camera leaves the
+    // uniform alone, which for a second view made with eyeOffset is taken to mean "left when shifted left"
+    p.left_eye = stereoEnabled ? (stereoLeft ? 1 : 0) : (eyeOffset < 0.0f ? 1 : 0);
 }
 
 int RayTracingMaster::SetShaderParameters(PtFrameParams &p)
@@ -127,6 +213,22 @@ int RayTracingMaster::SetShaderParameters(PtFrameParams &p)
     if (!oldCameras_.empty()) {
         int rc = check(pt_set_camera_history(ctx_, oldCameras_.data(), (int)oldCameras_.size()), "pt_set_camera_history");
         if (rc) return rc;
+    }
+    if (stereoEnabled) {
+        // :473-478 - the stereo branch keeps the lists only in the partial-frame modes 5 and 6, and there only across
+        // the frame that STARTS a cycle: every frame with counter % divisions != 0 clears them (the mono branch clears
+        // at == 0, and covers modes 5 .. 8)
+        if ((renderMode != 5 && renderMode != 6) || (divisions > 0 && counter_ % divisions != 0)) oldCameras_.clear();
+        // :480-485 - this eye's matrices: inverse projection, inverse view, view, projection
+        if (renderMode < 11 && renderMode != 1) {
+            PtCameraHistory h;
+            std::memcpy(h.camera_to_world, p.camera_to_world, sizeof h.camera_to_world);
+            std::memcpy(h.camera_inverse_projection, p.camera_inverse_projection, sizeof h.camera_inverse_projection);
+            std::memcpy(h.world_to_camera, stereoView, sizeof h.world_to_camera);
+            std::memcpy(h.camera_projection, stereoProj, sizeof h.camera_projection);
+            oldCameras_.push_back(h);
+        }
+        return PT_OK;
     }
     // :513-518 - outside the partial-frame modes the lists restart every frame; inside them at the start of a cycle
     if (renderMode < 5 || renderMode > 8 || (divisions > 0 && counter_ % divisions == 0)) oldCameras_.clear();
@@ -204,6 +306,14 @@ void ptm_camera_history_entry(const float eye[3], const float target[3], const f
 
 float ptm_frame_seed(uint32_t k) { return frame_seed(k); }
 
+int ptm_matrix_inverse(const float m[16], float out[16]) { return matrix_inverse(m, out) ? 1 : 0; }
+
+void ptm_camera_stereo_eye(const float eye[3], const float target[3], const float up[3], float fov, float aspect,
+                           float z_near, float z_far, float offset, float shear, float view[16], float proj[16])
+{
+    camera_stereo_eye(eye, target, up, fov, aspect, z_near, z_far, offset, shear, view, proj);
+}
+
 ptm_scene *ptm_scene_create(const char *name)
 {
     Scene *s = Scene::create(name ? name : "");
@@ -261,6 +371,24 @@ int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[
     m->m->fieldOfView = fov; m->m->eyeOffset = eye_offset;
     return PT_OK;
 }
+int ptm_master_set_stereo(ptm_master *m, int enabled, int left_eye, const float view[16], const float proj[16])
+{
+    RayTracingMaster &r = *m->m;
+    r.stereoEnabled = enabled != 0; r.stereoLeft = left_eye != 0;
+    if (enabled) {
+        if (!view || !proj) return PT_ERR_INVALID;
+        std::memcpy(r.stereoView, view, sizeof r.stereoView); std::memcpy(r.stereoProj, proj, sizeof r.stereoProj);
+    }
+    return PT_OK;
+}
+int ptm_master_register_object(ptm_master *m, const float *vertices, int n_vertices, const int32_t *indices, int n_indices, const float local_to_world[16])
+{
+    return m->m->RegisterObject(vertices, n_vertices, indices, n_indices, local_to_world);
+}
+int ptm_master_register_instance(ptm_master *m, int of_object, const float local_to_world[16]) { return m->m->RegisterInstance(of_object, local_to_world); }
+int ptm_master_unregister_object(ptm_master *m, int object) { return m->m->UnregisterObject(object); }
+int ptm_master_update_object(ptm_master *m, int object, const float local_to_world[16]) { return m->m->UpdateObject(object, local_to_world); }
+int ptm_master_object_count(const ptm_master *m) { return m->m->objectCount(); }
 int ptm_master_render(ptm_master *m) { return m->m->Render(); }
 int ptm_master_peek_params(ptm_master *m, PtFrameParams *out) { m->m->FillParams(*out); return PT_OK; }
 void ptm_master_reset_accumulation(ptm_master *m) { m->m->ResetAccumulation(); }

@@ -5,6 +5,7 @@
 // UnityEngine.Random) is supplied by scene.hpp.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/ptrace.h"
@@ -27,7 +28,13 @@ public:
     // ---- camera (Unity supplies these through Camera) -----------------------
     float eye[3] = {0, 5, -10}, target[3] = {0, 0, 0}, up[3] = {0, 1, 0};
     float fieldOfView = 60.0f, nearClip = 0.1f, farClip = 100.0f;  // TestScene.unity:851-853 near/far
-    float eyeOffset = 0.0f;                        // stereo: signed offset along camera right
+    float eyeOffset = 0.0f;                        // signed offset along camera right (a second view of the mono camera)
+    // _camera.stereoEnabled / stereoTargetEye and what GetStereoViewMatrix / GetStereoProjectionMatrix return for that
+    // eye (:459-467); column-major like Matrix4x4.  With stereoEnabled the branch :459-485 runs instead of :486-527.
+    bool stereoEnabled = false;
+    bool stereoLeft = true;                        // stereoTargetEye == StereoTargetEyeMask.Left
+    float stereoView[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float stereoProj[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
     explicit RayTracingMaster(int device);
     ~RayTracingMaster();
@@ -40,8 +47,16 @@ public:
 
     // OnEnable (RayTracingMaster.cs:139-152): _currentSample = 0; SetUpScene()
     int OnEnable(const Scene &scene, int sky_w, int sky_h);
-    // RegisterObject / UpdateObject (RayTracingMaster.cs:296-307) act on the scene the master was enabled with.
+    // RegisterObject / UpdateObject / UnregisterObject (RayTracingMaster.cs:296-313; called by RayTracingObject.cs:24-38
+    // from OnEnable / a changed transform / OnDisable).  An object is a mesh (object-space vertices, sub-mesh 0's
+    // indices) and a localToWorld matrix; RegisterObject returns its position in the list, as the reference does, and
+    // UnregisterObject moves the later objects up by one.  RegisterInstance adds an object that shares an earlier
+    // object's mesh (MeshFilter.sharedMesh).  Each sets _meshObjectsNeedRebuilding; the next Render() rebuilds.
+    int RegisterObject(const float *vertices, int n_vertices, const int32_t *indices, int n_indices, const float local_to_world[16]);
+    int RegisterInstance(int of_object, const float local_to_world[16]);
+    int UnregisterObject(int object);
     int UpdateObject(int object, const float local_to_world[16]);
+    int objectCount() const { return (int)rayTracingObjects_.size(); }
 
     int Render();                                       // :704-747 (+ :885-888)
     int SetShaderParameters(PtFrameParams &p);          // :455-540, :735-738 (uploads and then updates the camera history)
@@ -59,6 +74,10 @@ private:
 
     pt_context *ctx_ = nullptr;
     std::string error_;
+    struct Mesh { std::vector<float> vertices; std::vector<int32_t> indices; };   // Mesh.vertices, Mesh.GetIndices(0)
+    struct RayTracingObject { std::shared_ptr<const Mesh> mesh; float localToWorld[16]; };
+    std::vector<RayTracingObject> rayTracingObjects_;   // _rayTracingObjects :47
+    bool objectListChanged_ = false;                    // an object came or went since the last upload (not just a transform)
     std::vector<PtMeshObject> meshObjects_;             // _meshObjects  :50
     std::vector<float> vertices_;                       // _vertices     :51
     std::vector<int32_t> indices_;                      // _indices      :52

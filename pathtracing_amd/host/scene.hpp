@@ -32,6 +32,14 @@ void camera_look_at(const float eye[3], const float target[3], const float up[3]
 void camera_history_entry(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
                           float z_near, float z_far, PtCameraHistory *out);
 float frame_seed(uint32_t k);
+// Matrix4x4.inverse for a column-major 4x4 (Gauss-Jordan with partial pivoting in double precision); false, and the
+// identity in `out`, when the matrix is singular.
+bool matrix_inverse(const float m[16], float out[16]);
+// One eye of a stereo camera as Unity's Camera.GetStereoViewMatrix / GetStereoProjectionMatrix report it: the view
+// (world-to-camera) matrix of a look-at camera moved by `offset` along its right axis, and an off-axis OpenGL
+// projection whose frustum is shifted sideways by `shear` (element (0,2); 0 gives the symmetric frustum).
+void camera_stereo_eye(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                       float z_near, float z_far, float offset, float shear, float view[16], float proj[16]);
 
 // What the reference keeps in its static lists (RayTracingMaster.cs:47-52) plus the sphere list.
 struct Scene {

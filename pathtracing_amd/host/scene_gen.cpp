@@ -325,6 +325,50 @@ void camera_history_entry(const float eye[3], const float target[3], const float
     q[14] = (float)(-2.0 * z_far * z_near / (double)(z_far - z_near)); // (2,3)
 }
 
+bool matrix_inverse(const float m[16], float out[16])
+{
+    double a[4][8];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) { a[r][c] = m[c * 4 + r]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 4; r++)
+            if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (!(std::fabs(a[piv][col]) > 0.0)) {
+            for (int i = 0; i < 16; i++) out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+            return false;
+        }
+        if (piv != col)
+            for (int c = 0; c < 8; c++) std::swap(a[piv][c], a[col][c]);
+        const double d = a[col][col];
+        for (int c = 0; c < 8; c++) a[col][c] /= d;
+        for (int r = 0; r < 4; r++) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0)
+                for (int c = 0; c < 8; c++) a[r][c] -= f * a[col][c];
+        }
+    }
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) out[c * 4 + r] = (float)a[r][4 + c];
+    return true;
+}
+
+void camera_stereo_eye(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
+                       float z_near, float z_far, float offset, float shear, float view[16], float proj[16])
+{
+    // the mono camera's axes; the eye sits `offset` along the right axis and looks the same way (parallel axes)
+    float c2w[16], ip[16];
+    camera_look_at(eye, target, up, fov_y_deg, aspect, z_near, z_far, c2w, ip);
+    const float e[3] = {eye[0] + c2w[0] * offset, eye[1] + c2w[1] * offset, eye[2] + c2w[2] * offset};
+    const float t[3] = {target[0] + c2w[0] * offset, target[1] + c2w[1] * offset, target[2] + c2w[2] * offset};
+    PtCameraHistory h;
+    camera_history_entry(e, t, up, fov_y_deg, aspect, z_near, z_far, &h);
+    std::memcpy(view, h.world_to_camera, sizeof h.world_to_camera);
+    std::memcpy(proj, h.camera_projection, sizeof h.camera_projection);
+    proj[8] = shear;                                                   // (0,2): the frustum's sideways shift
+}
+
 float frame_seed(uint32_t k)
 {
     double v = 0.5 + (double)k * 0.6180339;

@@ -103,6 +103,30 @@ def camera_history_entry(eye, target, fov_deg, aspect, up=(0, 1, 0), z_near=0.1,
     return h
 
 
+def stereo_eye_matrices(eye, target, fov_deg, aspect, offset, shear, up=(0, 1, 0), z_near=0.1, z_far=100.0):
+    """(view, projection) of one stereo eye, each 16 floats column-major: what GetStereoViewMatrix / GetStereoProjectionMatrix return."""
+    e = np.asarray(eye, np.float32); t = np.asarray(target, np.float32); u = np.asarray(up, np.float32)
+    view = np.zeros(16, np.float32); proj = np.zeros(16, np.float32)
+    _ffi.ptmaster().ptm_camera_stereo_eye(e.ctypes.data, t.ctypes.data, u.ctypes.data, fov_deg, aspect, z_near, z_far, offset, shear,
+                                          view.ctypes.data, proj.ctypes.data)
+    return view, proj
+
+
+def matrix_inverse(m):
+    m = np.ascontiguousarray(m, np.float32).reshape(16); out = np.zeros(16, np.float32)
+    if not _ffi.ptmaster().ptm_matrix_inverse(m.ctypes.data, out.ctypes.data):
+        raise ValueError("singular matrix")
+    return out
+
+
+def stereo_history_entry(view, proj):
+    """The PtCameraHistory the stereo branch appends (RayTracingMaster.cs:480-485): inverse view, inverse projection, view, projection."""
+    h = PtCameraHistory()
+    h.camera_to_world[:] = matrix_inverse(view).tolist(); h.camera_inverse_projection[:] = matrix_inverse(proj).tolist()
+    h.world_to_camera[:] = np.asarray(view, np.float32).tolist(); h.camera_projection[:] = np.asarray(proj, np.float32).tolist()
+    return h
+
+
 def make_params(scene, width, height, *, seed=0.5, spp=1, max_bounces=8, depth=0, accumulate=0, sample_index=0,
                 tile=None, eye=None, target=None, fov=None, render_mode=1, accumulation_frames=0, divisions=0, counter=0, left_eye=0):
     """PtFrameParams for `scene`'s default (or the given) camera."""

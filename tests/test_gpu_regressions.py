@@ -88,3 +88,126 @@ def test_tree_that_could_overflow_the_stack_is_walked_as_a_two_child_tree(monkey
         finally:
             t.close()
     assert nodes["20"] > 1.5 * nodes[None]          # the two-child tree has about twice the nodes
+
+
+@pytest.mark.parametrize("left", [1, 0])
+def test_master_mirror_stereo_branch(left):
+    """The stereo branch of SetShaderParameters (RayTracingMaster.cs:459-485) through the C++ mirror, one master per eye
+    as the reference has one RayTracingMaster per eye camera: the eye's own view and (asymmetric) projection matrices,
+    inverted, become _CameraToWorld / _CameraInverseProjection; _leftEye is uploaded; and the camera lists follow the
+    stereo rule - kept only in renderMode 5 / 6 and only across the frame that starts a cycle (counter % divisions != 0
+    clears them, :473), where the mono branch clears at == 0.  renderMode 2, 4 (whose reprojection reads _leftEye) and 5
+    with a moving head; all targets against the oracle fed the uploaded parameters and a restatement of the list rule."""
+    lib = _ffi.ptmaster(); pt = _ffi.ptrace()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("xr")
+        W, H, D = 86, 92, 3                                  # the headset's 2064 x 2208 eye, scaled down
+        assert lib.ptm_master_load_scene(h, s.handle, 64, 32) == 0, lib.ptm_master_error(h)
+        orc = po.Oracle.from_scene(s, pa.procedural_sky(64, 32), accel=True)
+        ctx = lib.ptm_master_context(h)
+        lib.ptm_master_set_divisions(h, D)
+        res = np.zeros((H, W, 4), np.float32); res1 = np.zeros_like(res); res2 = np.zeros_like(res)
+        cams = [pa.PtCameraHistory() for _ in range(100)]; old = []
+        modes = [2, 2, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 2]
+        kept = []
+        for k, mode in enumerate(modes):
+            head = s.eye + np.array([0.05 * k, 0.01 * k, 0.08 * k], np.float32)
+            view, proj = pa.stereo_eye_matrices(head, s.target, 90.0, W / H, -0.011 if left else 0.011, 0.07 if left else -0.07)
+            lib.ptm_master_configure(h, W, H, 1, 4, 0, pa.PT_ACCUM_NONE, 4)
+            lib.ptm_master_set_render_mode(h, mode)
+            assert lib.ptm_master_set_stereo(h, 1, left, view.ctypes.data, proj.ctypes.data) == 0
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            assert p.left_eye == left and p.counter == k % D and p.render_mode == mode
+            assert np.allclose(np.array(p.camera_to_world), pa.matrix_inverse(view), atol=0) and \
+                np.allclose(np.array(p.camera_inverse_projection), pa.matrix_inverse(proj), atol=0)
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            cams[:len(old)] = old
+            orc.render_history(p, cams, W, H, res, res1, threads=8, result2=res2)
+            kept.append(len(old))
+            if mode not in (5, 6) or p.counter != 0:          # :473-478
+                old = []
+            if mode < 11 and mode != 1:                       # :480-485
+                old = old + [pa.stereo_history_entry(view, proj)]
+            got = [np.empty((H, W, 4), np.float32) for _ in range(3)]
+            assert pt.pt_read_result(ctx, got[0].ctypes.data) == 0 and pt.pt_read_converged(ctx, got[1].ctypes.data) == 0
+            assert pt.pt_read_target(ctx, pa.PT_TARGET_DENOISED, got[2].ctypes.data) == 0
+            for name, a, b in (("Result", got[0], res), ("Result1", got[1], res1), ("Result2", got[2], res2)):
+                assert _same(a, b), f"frame {k} (renderMode {mode}, {'left' if left else 'right'} eye): {name} differs"
+        # lists uploaded per frame: one camera in modes 2 / 4; in mode 5 two entries only on the frame after a cycle's start
+        assert kept == [0, 1, 1, 1, 1, 1, 1, 2, 1, 1, 2, 1, 1]
+        assert np.isfinite(res).all() and res[..., :3].max() > 0
+    finally:
+        lib.ptm_master_destroy(h)
+
+
+def test_master_mirror_objects_come_and_go():
+    """RegisterObject / UnregisterObject / UpdateObject after the first frame (RayTracingMaster.cs:296-313, what
+    RayTracingObject.cs:24-38 calls when a GameObject is enabled, disabled or moved): the next Render() rebuilds the mesh
+    buffers (:371-413) and the frame equals the oracle's render of the new object list - hit ids included, which number
+    the triangles in list order."""
+    lib = _ffi.ptmaster(); pt = _ffi.ptrace()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+        W, H = 96, 54
+        assert lib.ptm_master_load_scene(h, s.handle, 64, 32) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, W, H, 2, 4, 0, pa.PT_ACCUM_NONE, 4)
+        lib.ptm_master_set_render_mode(h, 1)
+        ctx = lib.ptm_master_context(h)
+        # the model's object list: (vertices, indices, matrix) per object, flattened the way RebuildMeshObjectBuffers does
+        objs = []
+        for o in s.objects:
+            idx = s.indices[o["offset"]:o["offset"] + o["count"]]
+            lo = int(idx.min())
+            objs.append((s.vertices[lo:int(idx.max()) + 1].copy(), (idx - lo).astype(np.int32), o["m"].copy()))
+        assert lib.ptm_master_object_count(h) == len(objs)
+
+        def check(what):
+            verts, index, table = [], [], np.zeros(len(objs), s.objects.dtype)
+            nv = ni = 0
+            for k, (v, i, m) in enumerate(objs):
+                verts.append(v); index.append(i + nv); table[k] = (m, ni, len(i)); nv += len(v); ni += len(i)
+            verts = np.concatenate(verts) if verts else np.zeros((0, 3), np.float32)
+            index = np.concatenate(index).astype(np.int32) if index else np.zeros(0, np.int32)
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            got = np.empty((H, W, 4), np.float32); ids = np.empty((H, W), np.int32)
+            assert pt.pt_read_result(ctx, got.ctypes.data) == 0 and pt.pt_read_hit_ids(ctx, ids.ctypes.data) == 0
+            want, want_ids, _ = po.Oracle(s.spheres, table, verts, index, sky=sky, accel=False).render(p, W, H, threads=8)
+            assert (ids == want_ids).all() and _same(got, want), what
+            return ids
+
+        ids0 = check("the scene as loaded")
+        # a new object appears: a tetrahedron in front of the camera
+        tv = np.array([[0, 0, 0], [1.5, 0, 0], [0, 1.5, 0], [0, 0, 1.5]], np.float32)
+        ti = np.array([0, 2, 1, 0, 1, 3, 0, 3, 2, 1, 2, 3], np.int32)
+        m = np.eye(4, dtype=np.float32); m[:3, 3] = (-0.5, 0.6, -2.0)
+        m = np.ascontiguousarray(m.T.reshape(16))
+        k = lib.ptm_master_register_object(h, tv.ctypes.data, len(tv), ti.ctypes.data, len(ti), m.ctypes.data)
+        assert k == len(objs)
+        objs.append((tv, ti, m))
+        ids1 = check("after RegisterObject")
+        n_before = 1 + len(s.spheres) + sum(len(i) for _, i, _ in objs[:-1]) // 3
+        assert (ids1 >= n_before).any() and not (ids0 >= n_before).any()          # the new triangles are seen, with the last ids
+        # it moves (a transform change: matrices only), and a second object sharing its mesh appears
+        m2 = m.copy(); m2[12:15] += np.array([0.4, 0.2, 0.3], np.float32)
+        assert lib.ptm_master_update_object(h, k, m2.ctypes.data) == 0
+        objs[k] = (tv, ti, m2)
+        check("after UpdateObject")
+        m3 = m.copy(); m3[12:15] += np.array([-1.2, 0.1, 0.5], np.float32)
+        assert lib.ptm_master_register_instance(h, k, m3.ctypes.data) == k + 1
+        objs.append((tv, ti, m3))
+        check("after RegisterInstance")
+        # the first object of the scene goes away: later objects move up and their triangles get lower ids
+        assert lib.ptm_master_unregister_object(h, 0) == 0
+        del objs[0]
+        assert lib.ptm_master_object_count(h) == len(objs)
+        check("after UnregisterObject")
+        assert lib.ptm_master_unregister_object(h, 99) != 0
+    finally:
+        lib.ptm_master_destroy(h)

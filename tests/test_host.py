@@ -213,3 +213,30 @@ def test_bvh_builder_invariants_and_stack_bound(tmp_path):
     assert out.returncode == 0 and "bvh_check ok" in out.stdout, out.stdout + out.stderr
     need = {ln.split("  ")[0].strip(): int(ln.split("stack need")[1].split("/")[1].split(",")[0]) for ln in out.stdout.splitlines() if "stack need" in ln}
     assert need["4000 points on a line"] > 92 and need["hall260k leaf 2"] < 60
+
+
+def test_matrix_inverse_and_stereo_eye_matrices():
+    """Matrix4x4.inverse as the stereo branch of SetShaderParameters uses it (RayTracingMaster.cs:463-466), and the per-eye
+    view / projection matrices the tests feed it."""
+    eye, target, fov, aspect = (1.0, 4.6, -6.0), (0.5, 1.0, 2.0), 90.0, 2064 / 2208
+    h = pa.camera_history_entry(eye, target, fov, aspect)
+    # inverse(cameraToWorld) = worldToCamera, inverse(projection) = the analytic inverse projection, and back
+    assert np.allclose(pa.matrix_inverse(h.camera_to_world), np.array(h.world_to_camera), atol=2e-6)
+    assert np.allclose(pa.matrix_inverse(h.camera_projection), np.array(h.camera_inverse_projection), rtol=1e-5, atol=1e-6)
+    m = np.array(h.camera_to_world, np.float32).reshape(4, 4).T
+    assert np.allclose(pa.matrix_inverse(h.camera_to_world).reshape(4, 4).T @ m, np.eye(4), atol=1e-5)
+    with pytest.raises(ValueError):
+        pa.matrix_inverse(np.zeros(16, np.float32))
+    # the two eyes: 0.022 apart along the camera's right axis (TestScene.unity:870), frusta sheared in opposite directions
+    vl, pl = pa.stereo_eye_matrices(eye, target, fov, aspect, -0.011, +0.07)
+    vr, pr = pa.stereo_eye_matrices(eye, target, fov, aspect, +0.011, -0.07)
+    cl, cr = pa.matrix_inverse(vl), pa.matrix_inverse(vr)
+    right = np.array(h.camera_to_world[0:3])
+    assert np.allclose(cr[12:15] - cl[12:15], 0.022 * right, atol=1e-5)
+    assert np.allclose(cl[0:12], cr[0:12], atol=1e-6)                       # parallel axes
+    assert pl[8] == np.float32(0.07) and pr[8] == np.float32(-0.07)
+    assert np.allclose(np.delete(pl, 8), np.delete(np.array(h.camera_projection, np.float32), 8))
+    # a sheared frustum's centre ray leaves the eye off-axis: clip (0, 0) comes from x = P02 / P00 per unit of distance ahead
+    ip = pa.matrix_inverse(pl).reshape(4, 4).T
+    centre = ip @ np.array([0, 0, 0, 1], np.float32)
+    assert abs(centre[0] / -centre[2] - 0.07 / pl[0]) < 1e-5
