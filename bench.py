@@ -44,6 +44,12 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="contexts per GPU that render alternate steps on their own streams, so that one dispatch's "
                          "ramp-up and tail are filled by the next (1 = one dispatch at a time)")
+    ap.add_argument("--split", choices=["spp", "eye", "rows"], default="spp",
+                    help="how N GPUs share the work: samples (default; one sum-reduce per job), stereo eyes (config 3: no "
+                         "collective), or row blocks of one frame (a gather)")
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="with --split spp: render this many samples per pixel in total, in frames of --spp, sharded over the "
+                         "ranks (time to image, strong scaling); 0 = every rank renders --steps frames (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-stereo", action="store_true", help="skip the 1080p stereo frame time (2 eyes, 1 spp, 4 bounces)")
@@ -64,7 +70,7 @@ def cpu_baseline(scene, sky, args):
     t0 = time.perf_counter()
     _, _, st = orc.render(p, W, H, threads=threads)
     dt = time.perf_counter() - t0
-    out = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    out = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "nproc": os.cpu_count(), "kind": "port",
            "sample": f"the whole {W}x{H} frame at {spp} spp (of {args.spp}), {args.bounces} bounces, "
                      f"oracle with its own median-split BVH, {st['rays']} rays in {dt:.1f} s"}
     # the reference's own algorithm has no acceleration structure: time the exhaustive loop on a much smaller sample
@@ -86,6 +92,28 @@ def cpu_baseline(scene, sky, args):
                               "sample": f"{tile2[2]}x{tile2[3]} tile, 1 spp, every triangle tested per ray as the "
                                         f"reference does, {st2['rays']} rays in {dt2:.1f} s"}
     return out
+
+
+def cpu_baseline_c1(args):
+    """Configuration 1 on the host cores: the sphere field of RayTracingMaster.cs:32-34 on the ground plane under the sky,
+    1920x1080, 8 bounces, 1 spp, by the oracle's loop over every sphere (the shader's own algorithm)."""
+    from oracle import pt_oracle as po
+    import pathtracing_amd as pa
+    scene = pa.Scene("spheres"); sky = pa.procedural_sky(2048, 1024)
+    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    W, H = 1920, 1080
+    orc = po.Oracle.from_scene(scene, sky, accel=False)
+    out = {}
+    for name, n, reps in (("all", threads, 8), ("one", 1, 1)):
+        t0 = time.perf_counter()
+        for k in range(reps):
+            _, _, st = orc.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=8), W, H, threads=n)
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt * 1e3, "cores": n}
+    return {"value": out["all"]["value"], "unit": "Mrays/s", "ms_per_frame": out["all"]["ms_per_frame"], "cores": threads,
+            "nproc": os.cpu_count(), "kind": "port", "single_thread": out["one"],
+            "sample": f"whole frames: spheres scene ({len(scene.spheres)} spheres + ground plane + sky), {W}x{H}, 8 bounces, 1 spp, "
+                      "exhaustive loop over the spheres as in the shader; mean of 8 frames"}
 
 
 # Arithmetic per unit of work, counted from the kernel source (one fused multiply-add = 2 flops; conversions, selects and
@@ -115,8 +143,27 @@ def measured_traffic(args):
     return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
 
 
-def main():
-    args = parse()
+def limiter_view(kernel):
+    """What the committed rocprofv3 PMC passes say limits the dominant kernel (profiles/r*_limiter.json, written from those
+    passes by tools/limiter_json.py): lanes active per vector instruction, how busy the vector ALUs and the texture
+    addressers are, the share of wave time spent waiting.  bench.py cannot profile itself; None without the file."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_limiter.json")))
+    if not found:
+        return None
+    t = json.load(open(found[-1]))
+    return t.get(kernel, t.get("path_sched_kernel<4>"))
+
+
+def gather_ceiling():
+    """The measured ceiling for what the traversal does - every lane chasing its own chain of 64-byte records, each fetched
+    as four 16-byte loads, table resident in L2 / Infinity Cache (tools/ubench/gather_rate, profiles/r*_gather_rate.json)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gather_rate.json")))
+    return json.load(open(found[-1])) if found else None
+
+
+def setup_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "PTRACE_BENCH_DEVICE" in os.environ:        # rehearsals of the N > 1 path on a box with fewer GPUs than ranks
@@ -124,10 +171,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-
     import torch
-    import pathtracing_amd as pa
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
@@ -141,7 +185,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
+    return rank, local_rank, world, dist
 
+
+def make_collective(dist):
     def collective(fn, tensor, **kw):
         """One collective on a CUDA tensor: directly on RCCL, through a host copy on the rehearsal backend."""
         if dist.get_backend() == "nccl":
@@ -150,10 +198,49 @@ def main():
             host = tensor.cpu()
             fn(host, **kw)
             tensor.copy_(host)
+    return collective
+
+
+def rank_table(torch, dist, collective, world, rank, local_rank, rays, dt):
+    """[device ordinal, Mrays/s] of every rank, so that the line shows N ranks took part."""
+    mine = torch.tensor([float(local_rank), rays / dt / 1e6], dtype=torch.float64, device="cuda")
+    if dist is None:
+        return [{"rank": 0, "device": local_rank, "mrays_per_s": float(mine[1])}]
+    allr = torch.zeros((world, 2), dtype=torch.float64, device="cuda")
+    allr[rank] = mine
+    collective(dist.all_reduce, allr, op=dist.ReduceOp.SUM)
+    return [{"rank": r, "device": int(allr[r, 0]), "mrays_per_s": float(allr[r, 1])} for r in range(world)]
+
+
+def relative_rmse(a, b):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(1e-30, np.sqrt(np.mean(b ** 2))))
+
+
+def main():
+    args = parse()
+    rank, local_rank, world, dist = setup_dist(args)
+    import torch
+    import pathtracing_amd as pa
+    from pathtracing_amd import distributed as D
+    collective = make_collective(dist) if dist is not None else None
+    if args.split == "eye":
+        return eye_split_job(args, pa, torch, dist, collective, rank, local_rank, world)
+    if args.split == "rows":
+        return row_split_job(args, pa, torch, D, dist, collective, rank, local_rank, world)
 
     W, H = args.width, args.height
     scene = pa.Scene(args.scene)
     sky = pa.procedural_sky(2048, 1024)
+    strong = args.total_spp > 0
+    if strong:
+        # time to image: --total-spp samples per pixel in frames of --spp samples (one _Seed per frame, the shader's RNG
+        # counter running on across a frame's samples), frame k rendered by rank k mod N
+        if args.total_spp % args.spp:
+            raise SystemExit("--total-spp must be a multiple of --spp (a frame is one dispatch of --spp samples)")
+        n_frames = args.total_spp // args.spp
+        my_frames = [k for k in range(n_frames) if k % world == rank]
+        args.steps = max(1, len(my_frames))
     # Every context is one "ComputeShader instance" with its own targets and stream.  A dispatch's persistent grid
     # fills the GPU, but its ramp-up and above all its tail (lanes finishing their last pixel) leave slots empty;
     # with several dispatches queued on different streams the next one's blocks move in as slots free up.
@@ -171,13 +258,17 @@ def main():
         trs.append(t); accums.append(acc); streams.append(st_i)
     tr = trs[0]
     total = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")     # this rank's sum; on rank 0 the job's sum
+    job = D.ShardedAccumulator(dst=0)
 
-    def run(first, count):
+    def frame_index(step):
+        return my_frames[step] if strong else D.sample_index(step, rank, world)
+
+    def run(first, count, timed):
         """`count` steps, dealt round-robin to the contexts: each adds its frames into its own accumulation buffer
-        inside the kernel's final write (sample indices (first + j)*world + rank -> distinct seeds); then the
-        buffers are added up and ONE sum-reduce takes them to rank 0."""
+        inside the kernel's final write (one _Seed per frame index); then the rank's buffers are added up and ONE
+        sum-reduce takes them to rank 0 (ShardedAccumulator: a weighted sum, the weight being the frames rendered)."""
         for j in range(count):
-            p = pa.make_params(scene, W, H, seed=pa.frame_seed((first + j) * world + rank), spp=args.spp,
+            p = pa.make_params(scene, W, H, seed=pa.frame_seed(frame_index(first + j)), spp=args.spp,
                                max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=j // n_ctx)
             trs[j % n_ctx].render(p)
         cur = torch.cuda.current_stream()
@@ -187,37 +278,49 @@ def main():
         total.zero_()
         for i in range(used):
             total.add_(accums[i])
-        if dist is not None:
-            collective(dist.reduce, total, dst=0, op=dist.ReduceOp.SUM)
+        acc = job if timed else D.ShardedAccumulator(dst=0)
+        acc.add(total, 1.0, weight=float(count), reduce=(lambda t, **kw: collective(dist.reduce, t, **kw)) if dist is not None else None,
+                all_reduce=(lambda t, **kw: collective(dist.all_reduce, t, **kw)) if dist is not None else None)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(0, args.warmup)             # also warms the collective up
+    warm = 0 if strong else args.warmup
+    if strong:
+        # warm-up frames are extra frames that are not part of the image
+        for j in range(args.warmup):
+            trs[j % n_ctx].render(pa.make_params(scene, W, H, seed=0.123, spp=args.spp, max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=0))
+        if dist is not None:
+            collective(dist.reduce, total, dst=0, op=dist.ReduceOp.SUM)
+    else:
+        run(0, args.warmup, False)             # also warms the collective up
     fence()
     for t in trs:
         t.stats()                   # close the statistics epoch of the warm-up
+    n_timed = len(my_frames) if strong else args.steps
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(warm, n_timed, True)
     fence()
     dt = time.perf_counter() - t0
     sts = [t.stats() for t in trs]
     st = dict(sts[0])
     for k in ("rays", "nodes_visited", "prims_tested", "paths"):
         st[k] = sum(x[k] for x in sts)
-    img_sum = total.clone() if rank == 0 else None
     # The dominant kernel by itself: the same launches one at a time on one context, timed by HIP events on its stream.
     # (In the region above up to n_ctx launches overlap, so a launch there lasts longer than it keeps the GPU busy.)
     solo_launches = 3
-    for j in range(solo_launches):
-        tr.render(pa.make_params(scene, W, H, seed=pa.frame_seed((args.warmup + j) * world + rank), spp=args.spp,
+    for j in range(solo_launches + 1):      # the first one lets the context measure its blocks' costs; it is not timed
+        if j == 1:
+            tr.stats()
+        tr.render(pa.make_params(scene, W, H, seed=pa.frame_seed(D.sample_index(args.warmup + j, rank, world)), spp=args.spp,
                                  max_bounces=args.bounces, accumulate=pa.PT_ACCUM_SUM, sample_index=j))
     solo = tr.stats()
 
     t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["rays"], st["nodes_visited"], st["prims_tested"], st["paths"]], dtype=torch.float64, device="cuda")
+    ranks = rank_table(torch, dist, collective, world, rank, local_rank, st["rays"], dt)
     if dist is not None:
         collective(dist.all_reduce, t_all, op=dist.ReduceOp.MAX)
         collective(dist.all_reduce, counts, op=dist.ReduceOp.SUM)
@@ -225,42 +328,83 @@ def main():
     rays, nodes, prims, paths = [float(x) for x in counts.tolist()]
 
     if rank == 0:
-        img = (img_sum / float(args.steps * world * 1.0)).cpu().numpy()   # every frame is already a mean over --spp samples
+        img = job.image().cpu().numpy()     # every frame is already a mean over --spp samples
+        frames_total = int(round(job.weight))
         mrays = rays / dt / 1e6
-        # roofline of the dominant kernel, path_sched_kernel<4>, from the solo launches: counted bytes per launch over the
-        # launch duration.  roofline["pipelined"] is the rate over the timed region, where n_ctx launches overlap.
-        launches = args.steps
+        # The same frame indices rendered by this rank alone, added up in index order: what the N-rank image must match
+        # (fp32 sums in another order: an RMSE, not bits).
+        rmse = None
+        if world > 1 and frames_total <= 256:
+            ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            tr.bind_target(pa.PT_TARGET_CONVERGED, ref.data_ptr())
+            order = range(frames_total) if strong else [D.sample_index(warm + j, r, world) for j in range(n_timed) for r in range(world)]
+            for j, k in enumerate(order):
+                tr.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=args.spp, max_bounces=args.bounces,
+                                         accumulate=pa.PT_ACCUM_SUM, sample_index=j))
+            tr.sync()
+            rmse = relative_rmse(img, (ref / float(frames_total)).cpu().numpy())
+            tr.bind_target(pa.PT_TARGET_CONVERGED, accums[0].data_ptr())
+            tr.stats()
+        # roofline of the dominant kernel from the solo launches: counted bytes per launch over the launch duration.
+        # roofline["pipelined"] is the rate over the timed region, where n_ctx launches overlap.
+        kernel = {0: "path_sched_kernel<4>", 1: "wf_trace<4>", 2: "path_pool_kernel<4>"}.get(
+            {"sched": 0, "mega": 0, "wavefront": 1, "wave": 1, "pool": 2}.get(os.environ.get("PTRACE_BACKEND", "sched"), 0))
+        launches = n_timed
         kernel_ms = solo["kernel_ms"] / solo_launches
         r_rank = solo["rays"]
         alg_bytes = (solo["nodes_visited"] * NODE_BYTES + solo["prims_tested"] * PRIM_BYTES) / solo_launches + W * H * PIXEL_BYTES
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         pipe_bytes = st["nodes_visited"] * NODE_BYTES + st["prims_tested"] * PRIM_BYTES + launches * W * H * PIXEL_BYTES
         pipe_achieved = pipe_bytes / dt / 1e9
+        single = r_rank / solo_launches / (kernel_ms * 1e-3) / 1e6
+        ceiling = gather_ceiling()
+        lane_loads = (solo["nodes_visited"] * 4 + solo["prims_tested"] * 3) / solo_launches      # 16-byte loads per lane
         out = {
             "metric": "Mrays/s (all bounces)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "steps": n_timed, "warmup": args.warmup, "ms_per_step": dt / n_timed * 1e3,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the same workload with one dispatch at a time on one stream - what a host that issues pt_render per frame gets,
+            # and the run the roofline object describes; `value` keeps --in-flight dispatches queued on as many streams
+            "value_single_dispatch": single,
             "config": {"workload": f"{args.scene} ({scene.n_triangles} triangles + {len(scene.spheres)} spheres + ground plane, "
                                    f"2048x1024 procedural sky) {W}x{H}, {args.bounces} bounces, {args.spp} spp per GPU per step",
-                       "parallelism": f"spp-sharded x{world}, scene replicated, in-kernel accumulation per GPU, one RCCL sum-reduce of the accumulation buffers per job"
+                       "parallelism": (f"{args.total_spp} spp in frames of {args.spp}, frame k on rank k mod {world}" if strong else f"spp-sharded x{world}")
+                       + ", scene replicated, in-kernel accumulation per GPU, one RCCL sum-reduce of the accumulation buffers per job"
                        if world > 1 else "single GPU",
-                       "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps},
+                       "rays_per_step": rays / n_timed / world, "paths_per_step": paths / n_timed / world,
+                       "frames_in_image": frames_total, "dispatches_in_flight": n_ctx},
+            "ranks": ranks, "world_size": dist.get_world_size() if dist is not None else 1,
+            "rmse_vs_one_rank": rmse,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
-                         "kernel": "path_sched_kernel<4>", "kernel_ms": kernel_ms, "launches_timed": solo_launches,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "launches_timed": solo_launches,
                          "pipelined": {"launches_in_flight": n_ctx, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBS,
                                        "effective_ms_per_launch": dt / launches * 1e3},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_ray": (solo["nodes_visited"] * NODE_BYTES + solo["prims_tested"] * PRIM_BYTES) / max(1, r_rank),
                          "nodes_per_ray": solo["nodes_visited"] / max(1, r_rank),
                          "prims_per_ray": solo["prims_tested"] / max(1, r_rank),
-                         "kernel_mrays_per_s": r_rank / solo_launches / (kernel_ms * 1e-3) / 1e6,
+                         "kernel_mrays_per_s": single,
+                         # The nominal HBM fraction above prices cache-resident gathers against DRAM bandwidth.  The ceilings
+                         # that apply: the scene (nodes + records ~ 17 MB) sits in L2 / Infinity Cache and every lane
+                         # fetches its own 64-byte record as 16-byte loads, for which the L1 sustains the measured rate below.
+                         "cache_gather": None if ceiling is None else {
+                             "achieved_tb_s": achieved / 1e3,
+                             "lane_loads_g_per_s": lane_loads / (kernel_ms * 1e-3) / 1e9,
+                             "lane_loads_ceiling_g_per_s": ceiling["lane_loads_g_per_s"],
+                             "frac_of_l1_gather_ceiling": lane_loads / (kernel_ms * 1e-3) / 1e9 / ceiling["lane_loads_g_per_s"],
+                             "ceiling_tb_s": ceiling["lane_loads_g_per_s"] * 16e-3,
+                             "guide_rows_from_l2_tb_s": [16.8, 18.8], "guide_rows_from_infinity_cache_tb_s": 8.6,
+                             "note": ceiling["note"]},
+                         "limiter": limiter_view(kernel),
                          # the other roofline the kernel could sit under: counted arithmetic against the fp32 vector peak
                          "valu": valu_view(solo, solo_launches, kernel_ms)},
             "image_mean_rgb": [float(x) for x in img[..., :3].reshape(-1, 3).mean(axis=0)],
             "image_crc": int(np.bitwise_xor.reduce(np.ascontiguousarray(img).view(np.uint32).reshape(-1))),
             "bvh": {"nodes": st["bvh_nodes"], "prims": st["bvh_prims"], "depth": st["bvh_depth"], "build_ms": st["bvh_build_ms"]},
         }
+        if strong:
+            out["time_to_image_ms"] = dt * 1e3
         # what a transform change costs: matrices in, primitive records and node boxes redone on the device
         tr.sync()
         t0 = time.perf_counter()
@@ -275,16 +419,156 @@ def main():
             out["blob70k_1080p"] = secondary_scene_rate(pa, torch, sky)
             out["ggx_1080p"] = secondary_scene_rate(pa, torch, sky, name=args.scene, ggx=True)
             out["reuse_primary_hit"] = secondary_scene_rate(pa, torch, sky, name=args.scene, reuse=True)
+            # 41 % of the headline's rays repeat a pixel's camera ray (the shader applies no jitter); this is the rate of
+            # the rays that differ, i.e. of incoherent traversal
+            out["value_distinct_rays"] = out["reuse_primary_hit"]["value"]
         if not args.no_reproj and world == 1:
             out["reproj_1080p"] = reproj_frame_time(pa, torch, scene, sky)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, args)
+            out["cpu_baseline_c1"] = cpu_baseline_c1(args)
         print(json.dumps(out), flush=True)
     for t in trs:
         t.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def eye_split_job(args, pa, torch, dist, collective, rank, local_rank, world):
+    """Configuration 3: a stereo XR frame, 2 x 2064x2208, 4 bounces, 1 spp + running-mean accumulation.  Rank r owns eye
+    r mod 2 of stereo pair r div 2 (its own accumulator, no reduce: the eyes go to different displays); with one rank both
+    eyes run on its GPU side by side, one context and stream each.  metric: ms per stereo frame (max over ranks)."""
+    W, H = (args.width, args.height) if (args.width, args.height) != (1920, 1080) else (2064, 2208)
+    scene = pa.Scene("xr"); sky = pa.procedural_sky(2048, 1024)
+    eyes = [0, 1] if world == 1 else [rank % 2]
+    sep = 0.022                                                   # TestScene.unity:870
+    trs = []
+    for e in eyes:
+        t = pa.PathTracer(local_rank)
+        t.load_scene(scene, sky); t.resize(W, H)
+        if len(eyes) == 2:
+            t.set_option("blocks_per_cu", 2)                      # two dispatches side by side on one GPU
+        t.trace_rays(np.array([[0, 5, 0, 0, -1, 0]], np.float32))
+        trs.append(t)
+
+    def frame(k):
+        for e, t in zip(eyes, trs):
+            off = np.array([(-0.5 + e) * sep, 0, 0], np.float32)
+            t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, accumulate=pa.PT_ACCUM_MEAN,
+                                    sample_index=min(k, 10), eye=scene.eye + off, target=scene.target + off, fov=90.0))
+
+    def fence():
+        for t in trs:
+            t.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        frame(k)
+    fence()
+    for t in trs:
+        t.stats()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        frame(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    rays = sum(t.stats()["rays"] for t in trs)
+    means = [float(t.read_converged()[..., :3].mean()) for t in trs]
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    r_all = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    ranks = rank_table(torch, dist, collective, world, rank, local_rank, rays, dt)
+    if dist is not None:
+        collective(dist.all_reduce, t_all, op=dist.ReduceOp.MAX)
+        collective(dist.all_reduce, r_all, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        pairs = max(1, world // 2)
+        print(json.dumps({
+            "metric": "ms/frame for a stereo XR frame (2 x %dx%d)" % (W, H), "value": float(t_all.item()) / args.steps * 1e3, "unit": "ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t_all.item()) / args.steps * 1e3,
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"xr scene, stereo {W}x{H} per eye, 4 bounces, 1 spp + running-mean accumulation",
+                       "parallelism": ("both eyes on one GPU, one context and stream per eye" if world == 1 else
+                                       f"eye r mod 2 of stereo pair r div 2 on rank r ({pairs} pair(s)); no collective in the frame"),
+                       "stereo_pairs": pairs},
+            "mrays_per_s": float(r_all.item()) / float(t_all.item()) / 1e6, "ranks": ranks,
+            "world_size": dist.get_world_size() if dist is not None else 1, "eye_image_means_rank0": means}), flush=True)
+    for t in trs:
+        t.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def row_split_job(args, pa, torch, D, dist, collective, rank, local_rank, world):
+    """Latency mode: one frame of the headline workload per step, rank r rendering its block of rows (tile_*), the blocks
+    gathered on rank 0 - disjoint pixels, no arithmetic, so the image equals the one-GPU image bit for bit (checked on
+    rank 0 against its own full render).  metric: ms per frame."""
+    W, H = args.width, args.height
+    scene = pa.Scene(args.scene); sky = pa.procedural_sky(2048, 1024)
+    t = pa.PathTracer(local_rank)
+    t.load_scene(scene, sky); t.resize(W, H)
+    t.trace_rays(np.array([[0, 5, 0, 0, -1, 0]], np.float32))
+    res = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    t.bind_target(pa.PT_TARGET_RESULT, res.data_ptr())
+    t.set_stream(torch.cuda.current_stream().cuda_stream)
+    y0, h = D.tile_rows(H, rank, world)
+    blocks = [D.tile_rows(H, r, world) for r in range(world)]
+    hmax = max(b[1] for b in blocks)
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+
+    def frame(k):
+        if h > 0:
+            t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=args.spp, max_bounces=args.bounces, tile=(0, y0, W, h)))
+        if dist is None:
+            return res
+        mine = torch.zeros((hmax, W, 4), dtype=torch.float32, device="cuda")     # equal-sized pieces for the gather
+        mine[:h] = res[y0:y0 + h]
+        pieces = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        if dist.get_backend() == "nccl":
+            dist.gather(mine, pieces, dst=0)
+        else:
+            host = mine.cpu(); hp = [p.cpu() for p in pieces] if pieces else None
+            dist.gather(host, hp, dst=0)
+            pieces = [p.cuda() for p in hp] if hp else None
+        if rank == 0:
+            for (by, bh), p in zip(blocks, pieces):
+                full[by:by + bh] = p[:bh]
+        return full
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        frame(k)
+    fence(); t.stats()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        img = frame(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    rays = t.stats()["rays"]
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda"); r_all = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    ranks = rank_table(torch, dist, collective, world, rank, local_rank, rays, dt)
+    if dist is not None:
+        collective(dist.all_reduce, t_all, op=dist.ReduceOp.MAX); collective(dist.all_reduce, r_all, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        got = img.cpu().numpy().copy()
+        t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(args.warmup + args.steps - 1), spp=args.spp, max_bounces=args.bounces))
+        t.sync()
+        same = bool((res.cpu().numpy().view(np.uint32) == got.view(np.uint32)).all())
+        print(json.dumps({
+            "metric": "ms/frame, rows split over the GPUs", "value": float(t_all.item()) / args.steps * 1e3, "unit": "ms", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t_all.item()) / args.steps * 1e3, "higher_is_better": False,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} {W}x{H}, {args.bounces} bounces, {args.spp} spp", "parallelism": f"contiguous row blocks x{world}, gathered on rank 0"},
+            "mrays_per_s": float(r_all.item()) / float(t_all.item()) / 1e6, "ranks": ranks, "world_size": dist.get_world_size() if dist is not None else 1,
+            "identical_to_one_gpu_image": same}), flush=True)
+    t.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def stereo_frame_time(pa, torch, frames=30):

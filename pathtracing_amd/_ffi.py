@@ -108,6 +108,8 @@ PTMASTER_SYMBOLS = {
     "ptm_master_unregister_object": (C.c_int, [C.c_void_p, C.c_int]),
     "ptm_master_update_object": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ptm_master_object_count": (C.c_int, [C.c_void_p]),
+    "ptm_master_set_render_scale": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "ptm_master_render_size": (None, [C.c_void_p, C.c_void_p]),
     "ptm_master_set_stereo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ptm_scene_create": (C.c_void_p, [C.c_char_p]),
     "ptm_scene_destroy": (None, [C.c_void_p]),

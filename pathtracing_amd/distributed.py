@@ -50,16 +50,19 @@ class ShardedAccumulator:
     total: torch.Tensor = None
     weight: float = 0.0
 
-    def add(self, frame, samples, group=None):
+    def add(self, frame, samples, group=None, weight=None, reduce=None, all_reduce=None):
+        """`frame` times `samples` goes into the sum and `weight` (default: `samples`) into the total weight.  `reduce` /
+        `all_reduce` replace the torch.distributed calls (e.g. to stage CUDA tensors through the host on a backend
+        that cannot take them)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         weighted = frame * float(samples) if samples != 1 else frame
-        w = torch.tensor([float(samples)], dtype=torch.float64, device=frame.device)
+        w = torch.tensor([float(samples if weight is None else weight)], dtype=torch.float64, device=frame.device)
         if world > 1:
             if weighted is frame:
                 weighted = frame.clone()
-            dist.reduce(weighted, dst=self.dst, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(w, op=dist.ReduceOp.SUM, group=group)
+            (reduce or dist.reduce)(weighted, dst=self.dst, op=dist.ReduceOp.SUM, group=group)
+            (all_reduce or dist.all_reduce)(w, op=dist.ReduceOp.SUM, group=group)
         if rank == self.dst:
             if self.total is None:
                 self.total = torch.zeros_like(weighted)

@@ -91,6 +91,12 @@ int ptm_master_set_render_mode(ptm_master *m, int render_mode);
 int ptm_master_set_divisions(ptm_master *m, int divisions);
 /* eye_offset: signed offset along the camera's right axis (stereo: -sep/2 left, +sep/2 right). */
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov_y_deg, float eye_offset);
+/* renderScale + GetRenderScale (RayTracingMaster.cs:86,585-597): the render size becomes Mathf.RoundToInt(screen size *
+ * renderScale) in place of the width / height of ptm_master_configure.  All targets get that size; the reference gives
+ * _converged and denoisedTex the screen size instead (:563-571), which differs for renderScale != 1 only
+ * (TestScene.unity:783 has 1). */
+int ptm_master_set_render_scale(ptm_master *m, int screen_width, int screen_height, float render_scale);
+void ptm_master_render_size(const ptm_master *m, int32_t size[2]);
 /* RayTracingMaster.RegisterObject / UnregisterObject / UpdateObject (RayTracingMaster.cs:296-313), which the reference's
  * RayTracingObject component calls from OnEnable, OnDisable and on a changed transform (RayTracingObject.cs:24-38).  A mesh
  * is object-space vertices (xyz) and the indices of its sub-mesh 0; register returns the object's position in the list

@@ -244,6 +244,13 @@ int RayTracingMaster::SetShaderParameters(PtFrameParams &p)
     return PT_OK;
 }
 
+void RayTracingMaster::GetRenderScale(int screen_width, int screen_height)
+{
+    // Mathf.RoundToInt rounds halves to the even neighbour, as nearbyint does in the default rounding mode
+    RenderHight = (int)std::nearbyint((double)((float)screen_height * renderScale));
+    RenderWidth = (int)std::nearbyint((double)((float)screen_width * renderScale));
+}
+
 int RayTracingMaster::InitRenderTexture()
 {
     if (targetW_ == RenderWidth && targetH_ == RenderHight) return PT_OK;   // :545
@@ -363,6 +370,14 @@ int ptm_master_configure(ptm_master *m, int width, int height, int spp, int max_
     r.depth = depth != 0; r.accumulate = accumulate; r.sampleFrames = sample_frames;
     return PT_OK;
 }
+int ptm_master_set_render_scale(ptm_master *m, int screen_width, int screen_height, float render_scale)
+{
+    if (!(render_scale > 0.0f) || screen_width < 0 || screen_height < 0) return PT_ERR_INVALID;
+    m->m->renderScale = render_scale;
+    m->m->GetRenderScale(screen_width, screen_height);
+    return PT_OK;
+}
+void ptm_master_render_size(const ptm_master *m, int32_t size[2]) { size[0] = m->m->RenderWidth; size[1] = m->m->RenderHight; }
 int ptm_master_set_render_mode(ptm_master *m, int render_mode) { m->m->renderMode = render_mode; return PT_OK; }
 int ptm_master_set_divisions(ptm_master *m, int divisions) { m->m->divisions = divisions; return PT_OK; }
 int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[3], float fov, float eye_offset)

@@ -17,6 +17,11 @@ class RayTracingMaster {
 public:
     // ---- inspector fields -------------------------------------------------
     int RenderWidth = 0, RenderHight = 0;        // RayTracingMaster.cs:87-88 (spelling as in the reference)
+    float renderScale = 1.0f;                     // :86 (TestScene.unity:783: 1)
+    // GetRenderScale (:585-597): RenderWidth / RenderHight = Mathf.RoundToInt(screen or eye-texture size * renderScale).
+    // The reference then makes _target that size and _converged / denoisedTex (int)(RenderWidth / renderScale) - the
+    // screen size again; here every target has the render size, which is the same thing for renderScale == 1.
+    void GetRenderScale(int screen_width, int screen_height);
     int samplesPerPixel = 1;                      // :85
     uint32_t sampleFrames = 3;                    // :74
     bool depth = false;                           // :686

@@ -211,3 +211,31 @@ def test_master_mirror_objects_come_and_go():
         assert lib.ptm_master_unregister_object(h, 99) != 0
     finally:
         lib.ptm_master_destroy(h)
+
+
+def test_master_mirror_render_scale():
+    """GetRenderScale (RayTracingMaster.cs:585-597): the render size is Mathf.RoundToInt(screen size * renderScale) - halves
+    go to the even neighbour - and the frame is rendered at that size."""
+    lib = _ffi.ptmaster(); pt = _ffi.ptrace()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        assert lib.ptm_master_load_scene(h, s.handle, 64, 32) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, 1, 1, 1, 4, 0, pa.PT_ACCUM_NONE, 4)
+        size = (C.c_int32 * 2)()
+        for screen, scale, want in (((64, 36), 1.0, (64, 36)), ((65, 37), 0.5, (32, 18)), ((63, 35), 0.5, (32, 18)), ((64, 36), 1.5, (96, 54))):
+            assert lib.ptm_master_set_render_scale(h, screen[0], screen[1], scale) == 0
+            lib.ptm_master_render_size(h, size)
+            assert tuple(size) == want, (screen, scale, tuple(size))
+        W, H = want
+        p = pa.PtFrameParams()
+        lib.ptm_master_peek_params(h, C.byref(p))
+        assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+        got = np.empty((H, W, 4), np.float32)
+        assert pt.pt_read_result(lib.ptm_master_context(h), got.ctypes.data) == 0
+        c, _, _ = po.Oracle.from_scene(s, pa.procedural_sky(64, 32), accel=False).render(p, W, H, threads=4)
+        assert _same(got, c)
+        assert lib.ptm_master_set_render_scale(h, 64, 36, 0.0) != 0
+    finally:
+        lib.ptm_master_destroy(h)
