@@ -26,6 +26,7 @@ struct SceneDev {
                                // NULL = the shader's hard-coded surface for every triangle (SH:250-253)
     int32_t sky_w, sky_h;
     int32_t n_nodes, n_prims, n_spheres;
+    int32_t n_nodes4;          // four-wide nodes (the stride between the node arrays of a PT_NODES_SOA build)
 };
 
 // How far outside a triangle the Moeller-Trumbore arithmetic (SH:192-230) can still report a hit.  Its barycentric
@@ -256,9 +257,18 @@ template <class ST>
 __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
                                               const ST &st, int &sp)
 {
+#ifdef PT_NODES_SOA
+    // measurement build: the same nodes as four arrays of 16-byte columns (origin + exponents | links | low planes and
+    // high x | high y, z), so that a visit touches four cache lines instead of one
+    const uint4 *q = sc.nodes4 + node;
+    const size_t col = (size_t)sc.n_nodes4;
+    const uint4 q0 = q[0], q1 = q[col], q2 = q[2 * col];
+    const uint2 q3 = *reinterpret_cast<const uint2 *>(q + 3 * col);
+#else
     const uint4 *q = sc.nodes4 + (size_t)node * 4;
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
     const uint2 q3 = *reinterpret_cast<const uint2 *>(q + 3);
+#endif
     const uint32_t meta = q0.w;
     // plane position along the ray: ((org + k * cell) - o) * inv = k * (cell * inv) + (org - o) * inv
     const float sx = __uint_as_float((meta & 0xffu) << 23) * r.ix;

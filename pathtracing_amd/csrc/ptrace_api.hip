@@ -422,7 +422,18 @@ int rebuild_scene(pt_context *ctx)
         ctx->refit_ready = !ctx->objects.empty();
     }
     if ((rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;
+#ifdef PT_NODES_SOA
+    {
+        const size_t n4 = bvh.nodes4.size();
+        std::vector<uint4> cols(n4 * 4);
+        for (size_t n = 0; n < n4; n++)
+            for (int c = 0; c < 4; c++) std::memcpy(&cols[(size_t)c * n4 + n], reinterpret_cast<const char *>(&bvh.nodes4[n]) + 16 * c, 16);
+        if ((rc = upload(ctx, ctx->d_nodes4, cols.data(), cols.size() * sizeof(uint4)))) return rc;
+        ctx->refit_ready = false;          // the refit kernels write whole records
+    }
+#else
     if ((rc = upload(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
+#endif
     ctx->n_nodes4 = (int)bvh.nodes4.size();
     if ((rc = upload(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
     if ((rc = upload(ctx, ctx->d_by_id, by_id.data(), by_id.size() * sizeof(uint32_t)))) return rc;
@@ -488,7 +499,7 @@ SceneDev scene_dev(const pt_context *ctx)
     sc.nodes = ctx->d_nodes; sc.nodes4 = ctx->d_nodes4; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
     sc.mesh_mat = ctx->d_mesh_mat;
     sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
-    sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres;
+    sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres; sc.n_nodes4 = ctx->n_nodes4;
     return sc;
 }
 
