@@ -15,6 +15,22 @@
 #pragma once
 #include "pt_device.hpp"
 
+#ifndef PT_POOL_K
+#define PT_POOL_K 2
+#endif
+#ifndef PT_POOL_SE
+#define PT_POOL_SE 8
+#endif
+#ifndef PT_POOL_HOME
+#define PT_POOL_HOME 0
+#endif
+#ifndef PT_POOL_WAVES
+#define PT_POOL_WAVES 3
+#endif
+#ifndef PT_POOL_TRAVERSE
+#define PT_POOL_TRAVERSE 0   // 1: one traversal phase (inner nodes and leaves voted inside it) instead of a node and a leaf phase
+#endif
+
 namespace ptrace {
 
 // K slots per lane, SE stack entries per slot in LDS (deeper ones in the global overflow buffer).
@@ -65,7 +81,67 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
         }
         if (n_inner + n_leaf + n_wait == 0) break;
 
-#if PT_POOL_HOME
+#if PT_POOL_TRAVERSE
+        // ---- 2. two phases only: traversal (inner nodes and leaves, voted lane by lane inside the phase) or Shade().
+        // A ray stays in its lane from the gather until its traversal ends, so gathers are several node steps apart.
+        const int phase = n_wait == 0 ? 1 : (n_inner + n_leaf == 0 ? 0
+                          : (min(n_inner + n_leaf, 64) * a.pool_vote_shade >= min(n_wait, 64) * a.pool_vote_node ? 1 : 0));
+        int n_sel = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const unsigned long long m = phase == 1 ? (m_inner[k] | m_leaf[k]) : m_wait[k];
+            const int rank = n_sel + (int)__popcll(m & ((1ull << lane) - 1ull));
+            if (((m >> lane) & 1ull) && rank < 64) sList[rank] = (uint32_t)(lane + 64 * k);
+            n_sel += __popcll(m);
+        }
+        n_sel = min(n_sel, 64);
+        __syncthreads();
+        const int slot = lane < n_sel ? (int)sList[lane] : -1;
+        __syncthreads();
+
+        if (phase == 1) {
+#ifdef PT_PROFILE_PHASES
+            PH_SWITCH(1)
+#endif
+            int32_t node = kDoneNode, idbest = 0; int sp = 0; float tbest = 0.0f; uint32_t recbest = 0;
+            f3 o = pt_make3(0, 0, 0), d = o;
+            RaySlabs r = {0, 0, 0, 0, 0, 0};
+            PStack st = {sStack, a.stack_overflow + gbase, n_slots};
+            if (slot >= 0) {
+                const float4 A = sA[slot], B = sB[slot], C = sC[slot];
+                node = sNode[slot]; sp = sSp[slot]; tbest = A.w; idbest = as_i(B.w); recbest = (uint32_t)as_i(C.w);
+                o = xyz(A); d = xyz(B);
+                r.ix = C.x; r.iy = C.y; r.iz = C.z; r.ox = -A.x * C.x; r.oy = -A.y * C.y; r.oz = -A.z * C.z;
+                st.lds = sStack + slot; st.overflow = a.stack_overflow + gbase + slot;
+            }
+            const int keep = max(1, (n_sel * a.pool_cont) >> 6);
+            for (;;) {
+                const int ni = __popcll(__ballot(node >= 0)), nl = __popcll(__ballot(is_leaf_ref(node)));
+                if (ni + nl < keep) break;
+                if (nl == 0 || ni * a.pool_vote_leaf > nl * 64) {
+#ifdef PT_PROFILE_PHASES
+                    PH_SWITCH(1) ph_rounds[1]++; ph_lanes[1] += ni;
+#endif
+                    if (node >= 0) { node = node_step<WIDE>(sc, node, r, tbest, st, sp); c_nodes++; }
+                } else {
+#ifdef PT_PROFILE_PHASES
+                    PH_SWITCH(2) ph_rounds[2]++; ph_lanes[2] += nl;
+#endif
+                    if (is_leaf_ref(node)) {
+                        uint32_t np = 0;
+                        node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, np);
+                        c_prims += np;
+                    }
+                }
+            }
+            if (slot >= 0) {
+                sA[slot].w = tbest; sB[slot].w = as_f(idbest); sC[slot].w = as_f((int32_t)recbest);
+                sNode[slot] = node; sSp[slot] = sp;
+            }
+            __syncthreads();
+            continue;
+        }
+#elif PT_POOL_HOME
         // ---- 2. / 3. home variant: a lane runs one of its own K slots (slot = lane + 64 k), so nothing moves between lanes
         // and every LDS access of the phases is conflict-free; the phase is the one most lanes can take part in
         unsigned long long l_inner = 0, l_leaf = 0, l_wait = 0;
@@ -111,6 +187,7 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
         __syncthreads();
 #endif
 
+#if !PT_POOL_TRAVERSE
         if (phase == 1) {
             // ================= node phase =================
 #ifdef PT_PROFILE_PHASES
@@ -160,6 +237,7 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
             continue;
         }
 
+#endif
         // ================= shade phase =================
 #ifdef PT_PROFILE_PHASES
         ph_rounds[0]++; ph_lanes[0] += n_sel; PH_SWITCH(0)
@@ -333,18 +411,6 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
 #endif
 }
 
-#ifndef PT_POOL_K
-#define PT_POOL_K 2
-#endif
-#ifndef PT_POOL_SE
-#define PT_POOL_SE 8
-#endif
-#ifndef PT_POOL_HOME
-#define PT_POOL_HOME 0
-#endif
-#ifndef PT_POOL_WAVES
-#define PT_POOL_WAVES 3
-#endif
 constexpr int kPoolK = PT_POOL_K;     // slots per lane
 constexpr int kPoolSE = PT_POOL_SE;   // stack entries per slot in LDS
 
