@@ -174,6 +174,11 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                jitter (RayTracingShader.compute:842), so the ray and its hit are the same every time.  Same image;
  *                PtStats.rays then counts only the rays actually traced.
  *   "refit"      1 (default): pt_update_transforms refits the four-wide tree on the device; 0: it rebuilds on the host.
+ *   "split_percent"  30 (default): before the tree is built, triangles that span a sixteenth of the scene or more are cut
+ *                into several references (boxes holding a part of the triangle each; a leaf still names the whole
+ *                triangle), at most this many additional references per hundred triangles of the scene; 0: none.  A
+ *                scene of evenly small triangles is left as it is; long beams and wall-sized triangles stop inflating
+ *                every node above them.  A refit keeps the cuts of objects that did not move.
  * All combinations produce the same image bit for bit. */
 int pt_set_option(pt_context *ctx, const char *name, int value);
 

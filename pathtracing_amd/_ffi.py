@@ -117,6 +117,9 @@ PTMASTER_SYMBOLS = {
     "ptm_scene_copy": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptm_scene_camera": (None, [C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float)]),
     "ptm_scene_add_obj": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "ptm_sky_load_hdr": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int]),
+    "ptm_sky_error": (C.c_char_p, []),
+    "ptm_master_set_sky_hdr": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ptm_master_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
     "ptm_master_destroy": (None, [C.c_void_p]),
     "ptm_master_error": (C.c_char_p, [C.c_void_p]),

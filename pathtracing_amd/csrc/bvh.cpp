@@ -332,4 +332,166 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
     return out;
 }
 
+// ---------------------------------------------------------------- reference splitting
+namespace {
+
+struct D3 { double v[3]; };
+
+struct Piece {
+    D3 poly[12]; int n;       // the part of the triangle inside the cuts made so far (a convex polygon)
+    Aabb box;
+};
+
+// The most important spatial-median plane of [lo, hi] (level 1 = its middle, level 2 = the quarters ...) strictly inside
+// (a, b); returns its level (1 .. 30) and position, or 0 when none exists at that resolution.
+int median_plane(double lo, double hi, double a, double b, double &pos)
+{
+    if (!(hi > lo) || !(b > a)) return 0;
+    // boxes are rounded outwards, so a plane within rounding distance of a face may only touch what is inside: keep clear of the faces
+    const double margin = 1e-4 * (b - a) + 4e-7 * std::max(std::fabs(a), std::fabs(b));
+    a += margin; b -= margin;
+    if (!(b > a)) return 0;
+    const double scale = 1073741824.0 / (hi - lo);     // 2^30 cells
+    double fa = (a - lo) * scale, fb = (b - lo) * scale;
+    if (!(fa >= 0.0)) fa = 0.0;
+    if (!(fb <= 1073741824.0)) fb = 1073741824.0;
+    const int64_t j0 = (int64_t)std::floor(fa) + 1, j1 = (int64_t)std::ceil(fb) - 1;     // plane indices strictly inside
+    if (j0 > j1) return 0;
+    const uint64_t x = (uint64_t)(j0 - 1) ^ (uint64_t)j1;
+    int h = 0;
+    while ((x >> (h + 1)) != 0) h++;
+    const int64_t j = (j1 >> h) << h;
+    pos = lo + (double)j / scale;
+    if (!(pos > a && pos < b)) return 0;
+    int level = 30 - h;
+    return level < 1 ? 1 : level;
+}
+
+Aabb poly_box(const Piece &p, const Aabb &within)
+{
+    Aabb b;
+    for (int k = 0; k < 3; k++) {
+        double lo = p.poly[0].v[k], hi = lo;
+        for (int i = 1; i < p.n; i++) { lo = std::min(lo, p.poly[i].v[k]); hi = std::max(hi, p.poly[i].v[k]); }
+        float fl = (float)lo, fh = (float)hi;
+        if ((double)fl > lo) fl = std::nextafterf(fl, -kInf);
+        if ((double)fh < hi) fh = std::nextafterf(fh, kInf);
+        b.lo[k] = std::max(fl, within.lo[k]); b.hi[k] = std::min(fh, within.hi[k]);
+    }
+    return b;
+}
+
+// Sutherland-Hodgman against the plane v[axis] = pos: `side` -1 keeps v[axis] <= pos, +1 keeps v[axis] >= pos.
+void clip(const Piece &in, int axis, double pos, int side, Piece &out)
+{
+    out.n = 0;
+    for (int i = 0; i < in.n; i++) {
+        const D3 &p = in.poly[i], &q = in.poly[(i + 1) % in.n];
+        const double dp = (p.v[axis] - pos) * side, dq = (q.v[axis] - pos) * side;
+        if (dp >= 0.0 && out.n < 12) out.poly[out.n++] = p;
+        if ((dp > 0.0 && dq < 0.0) || (dp < 0.0 && dq > 0.0)) {
+            const double t = dp / (dp - dq);
+            D3 r;
+            for (int k = 0; k < 3; k++) r.v[k] = p.v[k] + t * (q.v[k] - p.v[k]);
+            r.v[axis] = pos;
+            if (out.n < 12) out.poly[out.n++] = r;
+        }
+    }
+}
+
+void split_piece(const Piece &pc, int splits, const float slo[3], const float shi[3], uint32_t tri,
+                 std::vector<uint32_t> &ref_tri, std::vector<Aabb> &ref_box)
+{
+    if (splits > 0) {
+        int best_level = 0, best_axis = -1; double best_pos = 0.0, best_ext = -1.0;
+        for (int k = 0; k < 3; k++) {
+            double pos;
+            const int level = median_plane(slo[k], shi[k], pc.box.lo[k], pc.box.hi[k], pos);
+            const double ext = (double)pc.box.hi[k] - pc.box.lo[k];
+            if (level > 0 && (best_axis < 0 || level < best_level || (level == best_level && ext > best_ext))) {
+                best_level = level; best_axis = k; best_pos = pos; best_ext = ext;
+            }
+        }
+        if (best_axis >= 0) {
+            Piece l, r;
+            clip(pc, best_axis, best_pos, -1, l);
+            clip(pc, best_axis, best_pos, +1, r);
+            if (l.n >= 3 && r.n >= 3) {
+                l.box = poly_box(l, pc.box); r.box = poly_box(r, pc.box);
+                double wl = 0.0, wr = 0.0;
+                for (int k = 0; k < 3; k++) { wl = std::max(wl, (double)l.box.hi[k] - l.box.lo[k]); wr = std::max(wr, (double)r.box.hi[k] - r.box.lo[k]); }
+                int sl = wl + wr > 0.0 ? (int)std::floor((splits - 1) * wl / (wl + wr) + 0.5) : 0;
+                sl = std::max(0, std::min(splits - 1, sl));
+                split_piece(l, sl, slo, shi, tri, ref_tri, ref_box);
+                split_piece(r, splits - 1 - sl, slo, shi, tri, ref_tri, ref_box);
+                return;
+            }
+        }
+    }
+    ref_tri.push_back(tri); ref_box.push_back(pc.box);
+}
+
+}  // namespace
+
+void split_references(const float *tri9, const Aabb *boxes, size_t n_tris, const float scene_lo[3], const float scene_hi[3],
+                      float budget, std::vector<uint32_t> &ref_tri, std::vector<Aabb> &ref_box)
+{
+    const double kMaxSplits = 512.0;   // per triangle
+    double ext_max = 0.0;
+    for (int k = 0; k < 3; k++) ext_max = std::max(ext_max, (double)scene_hi[k] - scene_lo[k]);
+    const bool scene_ok = budget > 0.0f && ext_max > 0.0 && std::isfinite(ext_max);
+    // ---- the triangles worth cutting and their priorities
+    std::vector<uint32_t> cand; std::vector<float> prio;
+    for (size_t t = 0; scene_ok && t < n_tris; t++) {
+        const Aabb &b = boxes[t];
+        // only triangles that span a sixteenth of the scene: cutting the small ones of an evenly tessellated mesh adds
+        // references and nodes and removes no overlap
+        if (!(std::max(std::max((double)b.hi[0] - b.lo[0], (double)b.hi[1] - b.lo[1]), (double)b.hi[2] - b.lo[2]) >= ext_max / 16.0)) continue;
+        const float *v = tri9 + 9 * t;
+        bool ok = true;
+        for (int k = 0; k < 9; k++) ok = ok && std::fabs(v[k]) < kHugeCoord;     // false for NaN as well
+        if (!ok) continue;
+        int level = 0;
+        for (int k = 0; k < 3; k++) {
+            double pos;
+            const int l = median_plane(scene_lo[k], scene_hi[k], b.lo[k], b.hi[k], pos);
+            if (l > 0 && (level == 0 || l < level)) level = l;
+        }
+        if (level == 0) continue;
+        const double ex = ((double)b.hi[0] - b.lo[0]) / ext_max, ey = ((double)b.hi[1] - b.lo[1]) / ext_max, ez = ((double)b.hi[2] - b.lo[2]) / ext_max;
+        const double e1[3] = {((double)v[3] - v[0]) / ext_max, ((double)v[4] - v[1]) / ext_max, ((double)v[5] - v[2]) / ext_max};
+        const double e2[3] = {((double)v[6] - v[0]) / ext_max, ((double)v[7] - v[1]) / ext_max, ((double)v[8] - v[2]) / ext_max};
+        const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+        const double a_box = 2.0 * (ex * ey + ey * ez + ez * ex), a_ideal = std::fabs(nx) + std::fabs(ny) + std::fabs(nz);
+        const double d = a_box - a_ideal;
+        if (d > 0.0) { cand.push_back((uint32_t)t); prio.push_back((float)std::cbrt(std::ldexp(d, -level))); }
+    }
+    // ---- the scale D with sum(min(kMaxSplits, floor(D * priority))) <= budget * n_tris, by bisection
+    const double s_max = std::floor((double)budget * (double)n_tris);
+    double d_lo = 0.0;
+    if (!cand.empty() && s_max >= 1.0) {
+        double psum = 0.0;
+        for (float p : prio) psum += p;
+        auto total = [&](double D) { double s = 0.0; for (float p : prio) s += std::min(kMaxSplits, std::floor(D * p)); return s; };
+        double d_hi = 2.0 * s_max / psum + 1.0;
+        while (total(d_hi) <= s_max && d_hi < 1e30) d_hi *= 2.0;      // ends at 1e30 when every triangle is at its cap
+        for (int it = 0; it < 48; it++) {
+            const double mid = 0.5 * (d_lo + d_hi);
+            if (total(mid) <= s_max) d_lo = mid; else d_hi = mid;
+        }
+    }
+    ref_tri.reserve(ref_tri.size() + n_tris + (size_t)(cand.empty() ? 0.0 : s_max));
+    ref_box.reserve(ref_box.size() + n_tris + (size_t)(cand.empty() ? 0.0 : s_max));
+    size_t c = 0;
+    for (size_t t = 0; t < n_tris; t++) {
+        int splits = 0;
+        if (c < cand.size() && cand[c] == t) { splits = (int)std::min(kMaxSplits, std::floor(d_lo * prio[c])); c++; }
+        if (splits <= 0) { ref_tri.push_back((uint32_t)t); ref_box.push_back(boxes[t]); continue; }
+        Piece pc; pc.n = 3; pc.box = boxes[t];
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < 3; k++) pc.poly[i].v[k] = tri9[9 * t + 3 * i + k];
+        split_piece(pc, splits, scene_lo, scene_hi, (uint32_t)t, ref_tri, ref_box);
+    }
+}
+
 }  // namespace ptrace

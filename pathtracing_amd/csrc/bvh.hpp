@@ -6,6 +6,7 @@
 // construction of the traversal (padded boxes, (distance, id) ordering), the hit
 // that loop returns.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -71,5 +72,18 @@ struct BvhResult {
 // traversal_cost: SAH cost of visiting a node, in primitive tests; ranges of <= leaf_size primitives become
 // leaves when that is estimated cheaper than splitting them.
 BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost = 0.5f);
+
+// Reference splitting before the build: a large triangle's box is cut at spatial-median planes of the scene box into
+// several smaller boxes ("references"), each holding the part of the triangle on its side of the cuts, so that a long or
+// large triangle no longer inflates every node on the way down to it.  The tree is then built over references; a leaf
+// names the whole triangle, so a ray that enters any reference's box tests the triangle itself and the closest hit is
+// unchanged.  Which triangles are cut, how often and where follows Karras & Aila, "Fast parallel construction of
+// high-quality bounding volume hierarchies" (HPG 2013), section 4: priority cbrt(2^-level * (A_box - A_ideal)), cuts at the
+// most important median plane crossing the box, a budget of `budget` * n_tris additional references in total.
+//   tri9: world-space vertices, 9 floats per triangle; boxes: each triangle's exact (unpadded) box;
+//   ref_tri / ref_box: appended, one entry per reference (triangles that cannot be cut - a NaN, a coordinate beyond
+//   kHugeCoord - get their own box back).  Boxes are rounded outwards; the union of a triangle's boxes contains it.
+void split_references(const float *tri9, const Aabb *boxes, size_t n_tris, const float scene_lo[3], const float scene_hi[3],
+                      float budget, std::vector<uint32_t> &ref_tri, std::vector<Aabb> &ref_box);
 
 }  // namespace ptrace

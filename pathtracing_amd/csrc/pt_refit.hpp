@@ -21,6 +21,8 @@ struct RefitArgs {
     const float *matrices;    // 16 floats per object (UnityEngine.Matrix4x4 memory order)
     float4 *prims;            // the primitive records (pt_device.hpp)
     float *prim_box;          // 6 floats per slot: padded world-space box, lo then hi
+    const float *slot_clip;   // 6 floats per slot or null: the part of the triangle's box this reference stands for,
+    const float *build_matrices;   // valid while the object's matrix is bit for bit the one of the last full build
     uint4 *nodes4;            // Bvh4Node array
     float *node_box;          // 6 floats per node: exact union of its children's boxes
     const int32_t *level_nodes;   // node indices, deepest level first
@@ -63,6 +65,19 @@ __global__ __launch_bounds__(kRefitBlock) void refit_prims_kernel(const RefitArg
         if (!(v0.x == v0.x && v1.x == v1.x && v2.x == v2.x)) { lo[0] = -PT_INF; hi[0] = PT_INF; }
         if (!(v0.y == v0.y && v1.y == v1.y && v2.y == v2.y)) { lo[1] = -PT_INF; hi[1] = PT_INF; }
         if (!(v0.z == v0.z && v1.z == v1.z && v2.z == v2.z)) { lo[2] = -PT_INF; hi[2] = PT_INF; }   // made finite below
+        if (a.slot_clip) {
+            // a split triangle's reference keeps its cut box while its object stays where it was built; a moved object's
+            // references all take the whole triangle's box (still correct, and a full build cuts afresh)
+            const uint32_t *bm = reinterpret_cast<const uint32_t *>(a.build_matrices + 16 * (size_t)src.x);
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < 16; k++) same = same && bm[k] == __float_as_uint(mm[k]);
+            if (same)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = fmaxf(lo[k], a.slot_clip[(size_t)slot * 6 + k]); hi[k] = fminf(hi[k], a.slot_clip[(size_t)slot * 6 + 3 + k]);
+                }
+        }
     } else {
         const float4 c = a.prims[(size_t)slot * 3 + 0];
         const float r0 = a.prims[(size_t)slot * 3 + 1].x;

@@ -73,6 +73,10 @@ struct pt_context {
     int stack_need4 = 0;                           // most stack entries a ray can hold in the four-wide tree of the last build
     int stack_limit = kStackLds + kStackOverflow;  // entries a lane's stack holds; PTRACE_STACK_LIMIT lowers it (tests of the fallback)
     int n_nodes = 0, n_prims = 0, n_spheres = 0, sky_w = 0, sky_h = 0;
+    int n_slots = 0;                  // primitive records on the device: n_prims plus the extra references of split triangles
+    float split_budget = 0.3f;        // option "split_percent": additional references, per triangle of the scene, the build may spend on large triangles
+    float *d_slot_clip = nullptr;     // per slot, the unpadded box of its reference (only when some triangle was split)
+    float *d_build_matrices = nullptr;   // the matrices those boxes were cut under
 
     // targets
     int W = 0, H = 0;
@@ -319,10 +323,27 @@ int rebuild_scene(pt_context *ctx)
         const float r = std::sqrt(s.radius * s.radius + sphere_slack2);
         for (int k = 0; k < 3; k++) { boxes[i].lo[k] = s.position[k] - r; boxes[i].hi[k] = s.position[k] + r; }
     }
-    for (size_t i = 0; i < nP; i++) {
+    // ---- references: every sphere is one; a large triangle may be several (bvh.hpp, split_references)
+    static_assert(sizeof(Tri) == 36, "nine floats per triangle");
+    std::vector<uint32_t> ref_prim;
+    {
+        std::vector<Aabb> rboxes;
+        ref_prim.reserve(nP); rboxes.reserve(nP);
+        for (int i = 0; i < nS; i++) { ref_prim.push_back((uint32_t)i); rboxes.push_back(boxes[i]); }
+        std::vector<uint32_t> ref_tri;
+        split_references(tris.empty() ? nullptr : &tris[0].v0.x, boxes.data() + nS, tris.size(), ctx->scene_lo, ctx->scene_hi,
+                         ctx->split_budget, ref_tri, rboxes);
+        for (uint32_t t : ref_tri) ref_prim.push_back((uint32_t)nS + t);
+        boxes.swap(rboxes);
+    }
+    const size_t nR = ref_prim.size();
+    if (nR >= (1u << 28)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^28 primitive references");
+    std::vector<Aabb> clip;            // the unpadded boxes: what a refit may cut a static triangle's new box down to
+    if (nR != nP) clip = boxes;
+    for (size_t i = 0; i < nR; i++) {
         float own = 0.0f;      // what this primitive's own intersection arithmetic needs beyond the general padding
-        if (i >= (size_t)nS) {
-            const Tri &t = tris[i - nS];
+        if (ref_prim[i] >= (uint32_t)nS) {
+            const Tri &t = tris[ref_prim[i] - nS];
             own = triangle_fuzz(pt_sub3(t.v1, t.v0), pt_sub3(t.v2, t.v0), reach);
             if (!(own < kHugeCoord)) own = kHugeCoord;           // zero area, NaN: the huge box below
         }
@@ -343,10 +364,10 @@ int rebuild_scene(pt_context *ctx)
     BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct);
     auto t_built = std::chrono::steady_clock::now();
 
-    std::vector<float4> recs(nP * 3);
+    std::vector<float4> recs(nR * 3);
     std::vector<uint32_t> by_id(nP);
-    for (size_t slot = 0; slot < nP; slot++) {
-        uint32_t prim = bvh.order[slot];
+    for (size_t slot = 0; slot < nR; slot++) {
+        uint32_t prim = ref_prim[bvh.order[slot]];
         by_id[prim] = (uint32_t)slot;
         int32_t id = 1 + (int32_t)prim;
         float idf; std::memcpy(&idf, &id, 4);
@@ -386,11 +407,13 @@ int rebuild_scene(pt_context *ctx)
                 tri_obj[j] = (int32_t)o; tri_i0[j] = ctx->indices[i]; tri_i1[j] = ctx->indices[i + 1]; tri_i2[j] = ctx->indices[i + 2];
             }
         }
-        std::vector<int4> slot_src(nP);
-        for (size_t slot = 0; slot < nP; slot++) {
-            uint32_t prim = bvh.order[slot];
+        std::vector<int4> slot_src(nR);
+        std::vector<float> slot_clip(clip.empty() ? 0 : nR * 6);
+        for (size_t slot = 0; slot < nR; slot++) {
+            uint32_t prim = ref_prim[bvh.order[slot]];
             if ((int)prim < nS) slot_src[slot] = make_int4(-1, 0, 0, 0);
             else { size_t t = prim - nS; slot_src[slot] = make_int4(tri_obj[t], tri_i0[t], tri_i1[t], tri_i2[t]); }
+            if (!clip.empty()) { std::memcpy(&slot_clip[slot * 6], clip[bvh.order[slot]].lo, 12); std::memcpy(&slot_clip[slot * 6 + 3], clip[bvh.order[slot]].hi, 12); }
         }
         // nodes are stored parents first, so one forward pass gives every node its level
         const size_t nN = bvh.nodes4.size();
@@ -414,9 +437,11 @@ int rebuild_scene(pt_context *ctx)
         if ((rc = upload(ctx, ctx->d_slot_src, slot_src.data(), slot_src.size() * sizeof(int4)))) return rc;
         if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
         if ((rc = upload(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_slot_clip, slot_clip.data(), slot_clip.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_build_matrices, slot_clip.empty() ? nullptr : mats.data(), slot_clip.empty() ? 0 : mats.size() * sizeof(float)))) return rc;
         if ((rc = upload(ctx, ctx->d_level_nodes, level_nodes.data(), level_nodes.size() * sizeof(int32_t)))) return rc;
         free_dev(ctx->d_prim_box); free_dev(ctx->d_node_box);
-        PT_HIP(ctx, hipMalloc((void **)&ctx->d_prim_box, nP * 6 * sizeof(float)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_prim_box, nR * 6 * sizeof(float)));
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_node_box, nN * 6 * sizeof(float)));
         ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
         ctx->refit_ready = !ctx->objects.empty();
@@ -440,6 +465,7 @@ int rebuild_scene(pt_context *ctx)
     if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
     ctx->n_nodes = (int)bvh.nodes.size();
     ctx->n_prims = (int)nP;
+    ctx->n_slots = (int)nR;
     ctx->n_spheres = nS;
     ctx->stack_need4 = bvh.stack_need4;
     static_assert(kMaxDepth + 1 <= kStackLds + kStackOverflow, "the two-child tree must always fit the traversal stack");
@@ -449,7 +475,7 @@ int rebuild_scene(pt_context *ctx)
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING"))
-        std::fprintf(stderr, "scene build: prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n",
+        std::fprintf(stderr, "scene build: %zu primitives, %zu references, %zu nodes; prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n", nP, nR, bvh.nodes4.size(),
                      std::chrono::duration<float, std::milli>(t_prep - t0).count(), std::chrono::duration<float, std::milli>(t_built - t_prep).count(),
                      std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_built).count());
     ctx->scene_dirty = false;
@@ -675,6 +701,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : 4;
     if (const char *env = std::getenv("PTRACE_BLOCK_ORDER")) ctx->block_order = std::atoi(env) != 0;
+    if (const char *env = std::getenv("PTRACE_SPLIT")) ctx->split_budget = std::max(0.0f, std::min(4.0f, (float)std::atof(env)));
     if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = std::max(1, std::min(64, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_NODE")) ctx->vote_node = std::max(1, std::min(64, std::atoi(env)));
@@ -702,6 +729,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds); free_dev(ctx->own_display);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
+    free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
     for (int i = 0; i < pt_context::kCamRing; i++) {
@@ -805,8 +833,9 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     RefitArgs ra;
     ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
     ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
-    ra.pad = ctx->box_pad; ra.sphere_slack2 = ctx->sphere_slack2; ra.reach = ctx->sphere_reach; ra.n_prims = ctx->n_prims;
-    hipLaunchKernelGGL(refit_prims_kernel, dim3((ctx->n_prims + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra);
+    ra.pad = ctx->box_pad; ra.sphere_slack2 = ctx->sphere_slack2; ra.reach = ctx->sphere_reach; ra.n_prims = ctx->n_slots;
+    ra.slot_clip = ctx->d_slot_clip; ra.build_matrices = ctx->d_build_matrices;
+    hipLaunchKernelGGL(refit_prims_kernel, dim3((ctx->n_slots + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra);
     for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
         const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
         if (count > 0)
@@ -1264,6 +1293,12 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: refit must be 0 or 1");
         if (value && !ctx->refit) ctx->scene_dirty = true;   // the refit buffers are made by a full build
         ctx->refit = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "split_percent") == 0) {
+        if (value < 0 || value > 400) return fail(ctx, PT_ERR_INVALID, "pt_set_option: split_percent must be 0..400");
+        if (ctx->split_budget != 0.01f * (float)value) ctx->scene_dirty = true;
+        ctx->split_budget = 0.01f * (float)value;
         return PT_OK;
     }
     if (std::strcmp(name, "refill_threshold") == 0) {

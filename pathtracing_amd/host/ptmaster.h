@@ -29,6 +29,14 @@ int ptm_sphere_field(int sphere_seed, uint32_t spheres_max, float radius_min, fl
 /* Deterministic lat-long sky (vertical gradient + sun), RGBA32F, w*h texels. */
 void ptm_sky_procedural(int w, int h, float *rgba);
 
+/* A Radiance picture (.hdr, 32-bit_rle_rgbe) as _SkyboxTexture: what the reference's scene binds
+ * (Assets/HDRI/cape_hill_4k.hdr, RayTracingMaster.cs:25,457; import setting maxTextureSize 2048,
+ * cape_hill_4k.hdr.meta:34).  The picture is halved until neither side exceeds max_size (0: as it is) and stored
+ * bottom row first, RGBA32F, as pt_set_sky takes it.  Call with rgba = NULL to learn *w and *h, then with a buffer of
+ * capacity_texels >= w*h.  Returns 0, or -1 with the reason in ptm_sky_error() (thread-local). */
+int ptm_sky_load_hdr(const char *path, int max_size, int *w, int *h, float *rgba, int capacity_texels);
+const char *ptm_sky_error(void);
+
 /* Camera.cameraToWorldMatrix and Camera.projectionMatrix.inverse
  * (RayTracingMaster.cs:489-490) for a camera at `eye` looking at `target`:
  * OpenGL convention, camera looks down -Z. */
@@ -82,6 +90,8 @@ const char *ptm_master_error(const ptm_master *m);
 pt_context *ptm_master_context(ptm_master *m);
 /* OnEnable + scene upload: spheres and registered meshes of `s`, procedural sky of sky_w x sky_h. */
 int ptm_master_load_scene(ptm_master *m, const ptm_scene *s, int sky_w, int sky_h);
+/* SkyboxTexture from a Radiance picture (see ptm_sky_load_hdr; max_size 2048 is the asset's import setting). */
+int ptm_master_set_sky_hdr(ptm_master *m, const char *path, int max_size);
 /* Inspector fields (RayTracingMaster.cs:73-91, 686, 991) */
 int ptm_master_configure(ptm_master *m, int width, int height, int samples_per_pixel, int max_bounces,
                          int depth, int accumulate, uint32_t sample_frames);

@@ -68,6 +68,15 @@ int RayTracingMaster::OnEnable(const Scene &scene, int sky_w, int sky_h)
     return PT_OK;
 }
 
+// SkyboxTexture (:25), bound to the kernel at :457.
+int RayTracingMaster::SetSkyboxTexture(const char *hdr_path, int max_size)
+{
+    if (!ctx_) return PT_ERR_INVALID;
+    std::vector<float> sky; int w = 0, h = 0; std::string err;
+    if (!sky_load_hdr(hdr_path, max_size, w, h, sky, err)) { error_ = "SkyboxTexture: " + err; return PT_ERR_INVALID; }
+    return check(pt_set_sky(ctx_, sky.data(), w, h), "pt_set_sky");
+}
+
 int RayTracingMaster::SetUpScene(const Scene &scene)
 {
     // The sphere list was produced by ptm::sphere_field (the procedure of :317-359);
@@ -299,6 +308,22 @@ int ptm_sphere_field(int seed, uint32_t spheres_max, float rmin, float rmax, flo
 
 void ptm_sky_procedural(int w, int h, float *rgba) { sky_procedural(w, h, rgba); }
 
+static thread_local std::string g_sky_error;
+const char *ptm_sky_error(void) { return g_sky_error.c_str(); }
+int ptm_sky_load_hdr(const char *path, int max_size, int *w, int *h, float *rgba, int capacity_texels)
+{
+    g_sky_error.clear();
+    if (!path || !w || !h) { g_sky_error = "ptm_sky_load_hdr: NULL argument"; return -1; }
+    std::vector<float> img; int iw = 0, ih = 0;
+    if (!sky_load_hdr(path, max_size, iw, ih, img, g_sky_error)) return -1;
+    *w = iw; *h = ih;
+    if (rgba) {
+        if ((long long)capacity_texels < (long long)iw * ih) { g_sky_error = "ptm_sky_load_hdr: buffer too small"; return -1; }
+        std::memcpy(rgba, img.data(), img.size() * sizeof(float));
+    }
+    return 0;
+}
+
 void ptm_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov, float aspect,
                         float z_near, float z_far, float c2w[16], float ip[16])
 {
@@ -358,6 +383,12 @@ int ptm_master_create(int device, ptm_master **out)
 void ptm_master_destroy(ptm_master *m) { if (m) { delete m->m; delete m; } }
 const char *ptm_master_error(const ptm_master *m) { return m ? m->m->error().c_str() : "null master"; }
 pt_context *ptm_master_context(ptm_master *m) { return m->m->context(); }
+int ptm_master_set_sky_hdr(ptm_master *m, const char *path, int max_size)
+{
+    if (!m || !path) return PT_ERR_INVALID;
+    return m->m->SetSkyboxTexture(path, max_size);
+}
+
 int ptm_master_load_scene(ptm_master *m, const ptm_scene *s, int sky_w, int sky_h)
 {
     std::memcpy(m->m->eye, s->s->eye, 12); std::memcpy(m->m->target, s->s->target, 12); m->m->fieldOfView = s->s->fov;

@@ -52,6 +52,7 @@ public:
 
     // OnEnable (RayTracingMaster.cs:139-152): _currentSample = 0; SetUpScene()
     int OnEnable(const Scene &scene, int sky_w, int sky_h);
+    int SetSkyboxTexture(const char *hdr_path, int max_size = 2048);   // a Radiance .hdr picture in place of the procedural sky
     // RegisterObject / UpdateObject / UnregisterObject (RayTracingMaster.cs:296-313; called by RayTracingObject.cs:24-38
     // from OnEnable / a changed transform / OnDisable).  An object is a mesh (object-space vertices, sub-mesh 0's
     // indices) and a localToWorld matrix; RegisterObject returns its position in the list, as the reference does, and

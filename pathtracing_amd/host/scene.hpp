@@ -25,6 +25,8 @@ struct MeshBuilder {
 int sphere_field(int sphere_seed, uint32_t spheres_max, float rmin, float rmax, float placement_radius,
                  std::vector<PtSphere> &out);
 void sky_procedural(int w, int h, float *rgba);
+// A Radiance .hdr picture as a sky texture (row 0 at v = 0, i.e. the picture's bottom), halved until neither side exceeds max_size (0: as it is).
+bool sky_load_hdr(const char *path, int max_size, int &w, int &h, std::vector<float> &rgba, std::string &err);
 void camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
                     float z_near, float z_far, float c2w[16], float ip[16]);
 // The same camera as one element of the shader's four history arrays (cameraToWorld, inverse projection,

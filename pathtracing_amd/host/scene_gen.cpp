@@ -275,6 +275,91 @@ void sky_procedural(int w, int h, float *rgba)
     }
 }
 
+// Radiance picture (.hdr, "32-bit_rle_rgbe"): the format of the reference's SkyboxTexture asset (Assets/HDRI/cape_hill_4k.hdr,
+// bound at RayTracingMaster.cs:457).  Texels become mantissa * 2^(exponent - 136), alpha 1.  The file's first scanline is the top
+// of the picture (resolution "-Y h +X w") and the texture's v = 0 is its bottom, so scanlines are stored last first.  A
+// picture larger than max_size in either direction is halved (2x2 box) until it fits - the asset's import setting is
+// maxTextureSize 2048 (cape_hill_4k.hdr.meta:34); the importer's own resampling filter and its BC6H compression are not reproduced.
+bool sky_load_hdr(const char *path, int max_size, int &w, int &h, std::vector<float> &rgba, std::string &err)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return false; }
+    struct Closer { FILE *f; ~Closer() { std::fclose(f); } } closer{f};
+    char line[512];
+    if (!std::fgets(line, sizeof line, f) || (std::strncmp(line, "#?RADIANCE", 10) != 0 && std::strncmp(line, "#?RGBE", 6) != 0)) { err = "not a Radiance picture"; return false; }
+    bool format_ok = false;
+    for (;;) {
+        if (!std::fgets(line, sizeof line, f)) { err = "header ends early"; return false; }
+        if (line[0] == '\n' || (line[0] == '\r' && line[1] == '\n')) break;
+        if (std::strncmp(line, "FORMAT=", 7) == 0) {
+            if (std::strncmp(line + 7, "32-bit_rle_rgbe", 15) != 0) { err = "only FORMAT=32-bit_rle_rgbe is read"; return false; }
+            format_ok = true;
+        }
+    }
+    if (!format_ok) { err = "no FORMAT line"; return false; }
+    char sy = 0, sx = 0; int fh = 0, fw = 0;
+    if (!std::fgets(line, sizeof line, f) || std::sscanf(line, "%cY %d %cX %d", &sy, &fh, &sx, &fw) != 4 || (sy != '-' && sy != '+') || (sx != '-' && sx != '+') ||
+        fw <= 0 || fh <= 0 || fw > 32768 || fh > 32768) { err = "resolution line is not '-Y h +X w'"; return false; }
+    std::vector<unsigned char> scan((size_t)fw * 4);
+    std::vector<float> img((size_t)fw * fh * 4);
+    for (int y = 0; y < fh; y++) {
+        unsigned char head[4];
+        if (std::fread(head, 1, 4, f) != 4) { err = "pixel data ends early"; return false; }
+        if (head[0] == 2 && head[1] == 2 && !(head[2] & 0x80) && fw >= 8 && fw < 32768) {
+            // run-length encoded scanline: the four channels one after the other
+            if (((int)head[2] << 8 | head[3]) != fw) { err = "scanline width differs from the header"; return false; }
+            for (int c = 0; c < 4; c++)
+                for (int x = 0; x < fw;) {
+                    int n = std::fgetc(f);
+                    if (n == EOF) { err = "pixel data ends early"; return false; }
+                    if (n > 128) {
+                        n -= 128;
+                        const int v = std::fgetc(f);
+                        if (v == EOF || x + n > fw) { err = "bad run in a scanline"; return false; }
+                        while (n--) scan[(size_t)(x++) * 4 + c] = (unsigned char)v;
+                    } else {
+                        if (n == 0 || x + n > fw) { err = "bad run in a scanline"; return false; }
+                        while (n--) { const int v = std::fgetc(f); if (v == EOF) { err = "pixel data ends early"; return false; } scan[(size_t)(x++) * 4 + c] = (unsigned char)v; }
+                    }
+                }
+        } else {
+            // flat scanline; (1, 1, 1, n) repeats the previous texel n times (the old run-length form)
+            std::memcpy(scan.data(), head, 4);
+            int x = 1, shift = 0;
+            if (head[0] == 1 && head[1] == 1 && head[2] == 1) { err = "a scanline starts with a repeat"; return false; }
+            while (x < fw) {
+                unsigned char px[4];
+                if (std::fread(px, 1, 4, f) != 4) { err = "pixel data ends early"; return false; }
+                if (px[0] == 1 && px[1] == 1 && px[2] == 1) {
+                    long n = (long)px[3] << shift;
+                    if (x + n > fw) { err = "bad run in a scanline"; return false; }
+                    while (n--) { std::memcpy(&scan[(size_t)x * 4], &scan[(size_t)(x - 1) * 4], 4); x++; }
+                    shift += 8;
+                } else { std::memcpy(&scan[(size_t)x * 4], px, 4); x++; shift = 0; }
+            }
+        }
+        const int row = sy == '-' ? fh - 1 - y : y;
+        for (int x = 0; x < fw; x++) {
+            const unsigned char *q = &scan[(size_t)x * 4];
+            const float scale = q[3] ? std::ldexp(1.0f, (int)q[3] - 136) : 0.0f;
+            float *o = &img[((size_t)row * fw + (sx == '+' ? x : fw - 1 - x)) * 4];
+            o[0] = q[0] * scale; o[1] = q[1] * scale; o[2] = q[2] * scale; o[3] = 1.0f;
+        }
+    }
+    while (max_size > 0 && (fw > max_size || fh > max_size) && fw % 2 == 0 && fh % 2 == 0) {
+        const int nw = fw / 2, nh = fh / 2;
+        std::vector<float> half((size_t)nw * nh * 4);
+        for (int y = 0; y < nh; y++)
+            for (int x = 0; x < nw; x++)
+                for (int c = 0; c < 4; c++)
+                    half[((size_t)y * nw + x) * 4 + c] = 0.25f * (img[((size_t)(2 * y) * fw + 2 * x) * 4 + c] + img[((size_t)(2 * y) * fw + 2 * x + 1) * 4 + c] +
+                                                                img[((size_t)(2 * y + 1) * fw + 2 * x) * 4 + c] + img[((size_t)(2 * y + 1) * fw + 2 * x + 1) * 4 + c]);
+        img.swap(half); fw = nw; fh = nh;
+    }
+    w = fw; h = fh; rgba.swap(img);
+    return true;
+}
+
 void camera_look_at(const float eye[3], const float target[3], const float up[3], float fov_y_deg, float aspect,
                     float z_near, float z_far, float c2w[16], float ip[16])
 {

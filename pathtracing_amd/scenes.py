@@ -68,6 +68,19 @@ def procedural_sky(w=256, h=128):
     return sky
 
 
+def load_hdr(path, max_size=2048):
+    """A Radiance .hdr picture as a sky texture (H, W, 4) float32, bottom row first, halved until neither side exceeds
+    max_size (the reference asset's import setting, Assets/HDRI/cape_hill_4k.hdr.meta:34)."""
+    lib = _ffi.ptmaster()
+    w, h = C.c_int(0), C.c_int(0)
+    if lib.ptm_sky_load_hdr(str(path).encode(), int(max_size), C.byref(w), C.byref(h), None, 0) != 0:
+        raise ValueError(lib.ptm_sky_error().decode())
+    sky = np.zeros((h.value, w.value, 4), np.float32)
+    if lib.ptm_sky_load_hdr(str(path).encode(), int(max_size), C.byref(w), C.byref(h), sky.ctypes.data, w.value * h.value) != 0:
+        raise ValueError(lib.ptm_sky_error().decode())
+    return sky
+
+
 def frame_seed(k):
     return float(_ffi.ptmaster().ptm_frame_seed(int(k)))
 

@@ -1232,3 +1232,94 @@ def test_expensive_blocks_first_renders_the_same_image(tracer, sky_small):
                 outside = np.ones((H, W), bool); outside[y0:y0 + th, x0:x0 + tw] = False
                 assert (g[outside] == 0).all()
     tracer.set_option("block_order", 1)
+
+
+def _room_with_beams():
+    """The fixture's mesh inside a room of twelve wall-sized triangles, crossed by long thin beams at odd angles: what
+    reference splitting is for."""
+    f = pa.Scene("fixture")
+    verts = [np.array(f.vertices, np.float32).reshape(-1, 3)]
+    index = [np.array(f.indices, np.int32)]
+    objs = [(np.array(f.objects["m"][0], np.float32), 0, len(index[0]))]
+    nv, ni = len(verts[0]), len(index[0])
+
+    def box(lo, hi):
+        lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+        v = np.array([[(hi if (c >> k) & 1 else lo)[k] for k in range(3)] for c in range(8)], np.float32)
+        idx = []
+        for a, b, c, d in [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]:
+            idx += [a, b, c, a, c, d]
+        return v, np.array(idx, np.int32)
+
+    v, i = box((-16, -0.5, -16), (16, 14, 16))
+    verts.append(v); index.append(i + nv); objs.append((np.eye(4, dtype=np.float32).reshape(16), ni, len(i))); nv += len(v); ni += len(i)
+    rng = np.random.default_rng(8)
+    v, i = box((-12, -0.06, -0.06), (12, 0.06, 0.06))
+    verts.append(v); index.append(i + nv)                            # one beam mesh, many objects
+    for _ in range(14):
+        ya, za = np.radians(rng.uniform(0, 180)), np.radians(rng.uniform(-50, 50))
+        ry = np.array([[np.cos(ya), 0, np.sin(ya)], [0, 1, 0], [-np.sin(ya), 0, np.cos(ya)]])
+        rz = np.array([[np.cos(za), -np.sin(za), 0], [np.sin(za), np.cos(za), 0], [0, 0, 1]])
+        m = np.eye(4, dtype=np.float32); m[:3, :3] = ry @ rz; m[:3, 3] = (rng.uniform(-4, 4), rng.uniform(2, 9), rng.uniform(-4, 4))
+        objs.append((m.T.reshape(16), ni, len(i)))
+    return f, np.array(objs, f.objects.dtype), np.concatenate(verts), np.concatenate(index)
+
+
+def test_large_triangles_are_split_into_references(tracer, sky_small):
+    """Option "split_percent": wall-sized triangles and long beams are cut into several boxes before the tree is built.
+    The image, the hit ids and the ray count equal the oracle's and those of an unsplit build bit for bit; the rays
+    visit fewer nodes and test fewer primitives; a refit that moves one beam keeps the other objects' cuts, still equals
+    the oracle and equals a full build of the moved scene; the exhaustive loop sees every primitive once."""
+    f, objs, verts, index = _room_with_beams()
+    W, H = 128, 72
+    cam = dict(eye=(2.0, 6.0, -13.0), target=(0.0, 4.0, 0.0), fov=60)
+    p = pa.make_params(f, W, H, spp=2, max_bounces=5, seed=0.41, **cam)
+    orc = po.Oracle(f.spheres, objs, verts, index, sky=sky_small)
+    c, cid, cst = orc.render(p, W, H, threads=4)
+    tracer.set_spheres(f.spheres); tracer.set_meshes(objs, verts, index); tracer.set_sky(sky_small)
+    tracer.resize(W, H)
+    seen = {}
+    try:
+        for percent in (0, 30, 400):
+            tracer.set_option("split_percent", percent)
+            tracer.stats()                                                   # a fresh epoch for the counters
+            tracer.render(p)
+            g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+            assert (gid == cid).all(), percent
+            _assert_same_image(g, c, f"split_percent {percent}")
+            assert st["rays"] == cst["rays"]
+            seen[percent] = (st["nodes_visited"], st["prims_tested"], st["bvh_nodes"], st["bvh_prims"])
+        assert seen[0][3] == seen[30][3] == seen[400][3]                     # primitives, not references
+        assert seen[30][2] > seen[0][2] and seen[400][2] > seen[30][2]       # more references, more nodes
+        assert seen[30][0] < 0.85 * seen[0][0] and seen[30][1] < 0.6 * seen[0][1], seen
+        assert seen[400][0] < 0.7 * seen[0][0] and seen[400][1] < 0.2 * seen[0][1], seen
+        tracer.set_option("split_percent", 30)
+        tracer.stats()
+        tracer.render(p); before = tracer.stats()["nodes_visited"]
+        # the same matrices again: a refit, and every reference keeps its cut box
+        tracer.update_transforms(objs)
+        tracer.render(p)
+        _assert_same_image(tracer.read_result(), c, "refit with unchanged matrices")
+        assert tracer.stats()["nodes_visited"] == before
+        # one beam moves
+        moved = objs.copy()
+        m = moved["m"][5].reshape(4, 4).T.copy(); m[:3, 3] += (1.5, -0.5, 2.0); moved["m"][5] = m.T.reshape(16)
+        tracer.update_transforms(moved)
+        tracer.render(p)
+        g = tracer.read_result(); gid = tracer.read_hit_ids(); after = tracer.stats()["nodes_visited"]
+        c2, cid2, _ = po.Oracle(f.spheres, moved, verts, index, sky=sky_small).render(p, W, H, threads=4)
+        assert (gid == cid2).all()
+        _assert_same_image(g, c2, "refit after a beam moved")
+        assert after < 1.5 * before, (after, before)               # the other objects kept their cuts
+        rng = np.random.default_rng(2)
+        o = rng.uniform(-10, 10, (300, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.5, 12, 300)
+        d = rng.normal(size=(300, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        od = np.concatenate([o, d], 1)
+        ib, tb = tracer.trace_rays(od); ie, te = tracer.trace_rays(od, brute_force=True)
+        assert (ib == ie).all() and (_bits(tb) == _bits(te)).all()
+        tracer.set_option("refit", 0)
+        tracer.update_transforms(moved)
+        tracer.render(p)
+        _assert_same_image(tracer.read_result(), g, "full build of the moved scene")
+    finally:
+        tracer.set_option("refit", 1); tracer.set_option("split_percent", 30)

@@ -240,3 +240,66 @@ def test_matrix_inverse_and_stereo_eye_matrices():
     ip = pa.matrix_inverse(pl).reshape(4, 4).T
     centre = ip @ np.array([0, 0, 0, 1], np.float32)
     assert abs(centre[0] / -centre[2] - 0.07 / pl[0]) < 1e-5
+
+
+def _write_hdr(path, rgbe, rle=True, flip_header=False):
+    """A Radiance picture from (H, W, 4) uint8 RGBE texels, top scanline first; new-style run-length coding or flat."""
+    h, w, _ = rgbe.shape
+    out = bytearray(b"#?RADIANCE\n# written by the test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n")
+    out += (f"+Y {h} +X {w}\n" if flip_header else f"-Y {h} +X {w}\n").encode()
+    for y in range(h):
+        if not rle:
+            out += rgbe[y].tobytes()
+            continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row = rgbe[y, :, c]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, row[x]]); x += run
+                else:
+                    lit = 1
+                    while x + lit < w and lit < 128 and not (x + lit + 2 < w and row[x + lit] == row[x + lit + 1] == row[x + lit + 2]):
+                        lit += 1
+                    out += bytes([lit]) + row[x:x + lit].tobytes(); x += lit
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+def test_radiance_hdr_sky_loader(tmp_path):
+    """The format of the reference's SkyboxTexture asset (Assets/HDRI/cape_hill_4k.hdr; the file itself is not in the
+    checkout): run-length coded and flat scanlines decode to mantissa * 2^(e - 136), the picture's bottom scanline becomes
+    row 0 (v = 0), a picture over the size limit is halved by 2x2 means, and broken files are refused with a reason."""
+    rng = np.random.default_rng(4)
+    H, W = 16, 32
+    rgbe = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    rgbe[:, :, 3] = rng.integers(120, 140, (H, W))
+    rgbe[3, 5:20] = rgbe[3, 5]                        # a long run
+    rgbe[7, :, :] = (10, 20, 30, 129)                 # a constant scanline
+    rgbe[2, 4, 3] = 0                                 # exponent 0: black
+    want = rgbe[:, :, :3].astype(np.float32) * np.ldexp(np.float32(1), rgbe[:, :, 3].astype(np.int32) - 136)[..., None]
+    want[rgbe[:, :, 3] == 0] = 0
+    want = np.concatenate([want, np.ones((H, W, 1), np.float32)], 2)[::-1]      # bottom scanline first
+    for rle in (True, False):
+        path = tmp_path / f"sky_{int(rle)}.hdr"
+        _write_hdr(path, rgbe, rle=rle)
+        got = pa.load_hdr(path, max_size=0)
+        assert got.shape == (H, W, 4) and (got == want).all()
+    _write_hdr(tmp_path / "up.hdr", rgbe, flip_header=True)                      # "+Y": the file already starts at the bottom
+    assert (pa.load_hdr(tmp_path / "up.hdr", max_size=0) == want[::-1]).all()
+    half = pa.load_hdr(tmp_path / "sky_1.hdr", max_size=16)
+    assert half.shape == (8, 16, 4)
+    assert np.allclose(half, 0.25 * (want[0::2, 0::2] + want[0::2, 1::2] + want[1::2, 0::2] + want[1::2, 1::2]), rtol=1e-6)
+    assert pa.load_hdr(tmp_path / "sky_1.hdr").shape == (H, W, 4)                # default limit 2048: untouched
+    # refusals
+    raw = (tmp_path / "sky_1.hdr").read_bytes()
+    (tmp_path / "short.hdr").write_bytes(raw[:len(raw) // 2])
+    (tmp_path / "magic.hdr").write_bytes(b"P6\n" + raw)
+    (tmp_path / "xyze.hdr").write_bytes(raw.replace(b"32-bit_rle_rgbe", b"32-bit_rle_xyze"))
+    for name, why in (("short.hdr", "ends early"), ("magic.hdr", "not a Radiance"), ("xyze.hdr", "32-bit_rle_rgbe"), ("absent.hdr", "cannot open")):
+        with pytest.raises(ValueError, match=why):
+            pa.load_hdr(tmp_path / name)

@@ -5,6 +5,7 @@
 // leaf, that every (dequantised) child box contains the boxes below it, and that the depth stays within kMaxDepth.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <memory>
 #include <random>
@@ -67,9 +68,81 @@ static int check(const char *what, const std::vector<Aabb> &boxes, int leaf)
     return bad;
 }
 
+// split_references: every point of a triangle lies in one of the triangle's reference boxes, the number of additional
+// references stays within the budget, triangles it must leave alone come back as they were.
+static int check_split(const char *what, const std::vector<float> &tri9, float budget, bool expect_splits)
+{
+    const size_t n = tri9.size() / 9;
+    std::vector<Aabb> boxes(n);
+    float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t t = 0; t < n; t++)
+        for (int k = 0; k < 3; k++) {
+            const float *v = &tri9[9 * t];
+            boxes[t].lo[k] = std::min(v[k], std::min(v[3 + k], v[6 + k])); boxes[t].hi[k] = std::max(v[k], std::max(v[3 + k], v[6 + k]));
+            if (std::fabs(boxes[t].lo[k]) < ptrace::kHugeCoord) slo[k] = std::min(slo[k], boxes[t].lo[k]);
+            if (std::fabs(boxes[t].hi[k]) < ptrace::kHugeCoord) shi[k] = std::max(shi[k], boxes[t].hi[k]);
+        }
+    std::vector<uint32_t> ref_tri; std::vector<Aabb> ref_box;
+    split_references(tri9.data(), boxes.data(), n, slo, shi, budget, ref_tri, ref_box);
+    int bad = 0;
+    if (ref_tri.size() != ref_box.size() || ref_tri.size() < n || (double)ref_tri.size() > (double)n + std::floor((double)budget * n)) { std::printf("%s: %zu references for %zu triangles\n", what, ref_tri.size(), n); bad++; }
+    if (expect_splits != (ref_tri.size() > n)) { std::printf("%s: %s\n", what, expect_splits ? "nothing was split" : "something was split"); bad++; }
+    std::vector<std::vector<Aabb>> per(n);
+    for (size_t r = 0; r < ref_tri.size(); r++) {
+        if (ref_tri[r] >= n) { bad++; continue; }
+        if (r > 0 && ref_tri[r] < ref_tri[r - 1]) { std::printf("%s: references out of triangle order\n", what); bad++; }
+        per[ref_tri[r]].push_back(ref_box[r]);
+        for (int k = 0; k < 3; k++)
+            if (ref_box[r].lo[k] < boxes[ref_tri[r]].lo[k] || ref_box[r].hi[k] > boxes[ref_tri[r]].hi[k]) { std::printf("%s: a reference box leaves its triangle's box\n", what); bad++; }
+    }
+    std::mt19937 rng(11);
+    std::uniform_real_distribution<double> u(0.0, 1.0);
+    for (size_t t = 0; t < n; t++) {
+        if (per[t].empty()) { std::printf("%s: triangle %zu lost\n", what, t); bad++; continue; }
+        if (per[t].size() == 1) { if (std::memcmp(&per[t][0], &boxes[t], sizeof(Aabb)) != 0) { std::printf("%s: unsplit triangle %zu changed its box\n", what, t); bad++; } continue; }
+        const float *v = &tri9[9 * t];
+        for (int s = 0; s < 200; s++) {
+            double a = u(rng), b = u(rng);
+            if (s < 3) { a = s == 1; b = s == 2; }        // the corners too
+            else if (a + b > 1.0) { a = 1.0 - a; b = 1.0 - b; }
+            double p[3];
+            for (int k = 0; k < 3; k++) p[k] = (double)v[k] + a * ((double)v[3 + k] - v[k]) + b * ((double)v[6 + k] - v[k]);
+            bool in = false;
+            for (const Aabb &bx : per[t]) {
+                bool here = true;
+                for (int k = 0; k < 3; k++) { const double tol = 1e-6 * (std::fabs(p[k]) + 1.0); here = here && p[k] >= bx.lo[k] - tol && p[k] <= bx.hi[k] + tol; }
+                in = in || here;
+            }
+            if (!in) { std::printf("%s: a point of triangle %zu is in none of its %zu boxes\n", what, t, per[t].size()); bad++; break; }
+        }
+    }
+    std::printf("%-28s %zu triangles -> %zu references\n", what, n, ref_tri.size());
+    return bad;
+}
+
 int main()
 {
     int bad = 0;
+    {
+        std::mt19937 rng(9);
+        std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+        std::vector<float> small, mixed, odd;
+        for (int i = 0; i < 3000; i++) { float c[3] = {10 * u(rng), 10 * u(rng), 10 * u(rng)}; for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) small.push_back(c[k] + 0.1f * u(rng)); }
+        mixed = small;
+        for (int i = 0; i < 60; i++) for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) mixed.push_back(12 * u(rng));      // large, any orientation
+        for (float y : {-10.0f, 10.0f}) { const float q[9] = {-10, y, -10, 10, y, -10, 10, y, 10}; mixed.insert(mixed.end(), q, q + 9); }   // axis-aligned walls
+        { const float sliver[9] = {-9, 0, 0, 9, 0.001f, 0, 9, 0, 0.001f}; mixed.insert(mixed.end(), sliver, sliver + 9); }
+        odd = mixed;
+        { const float nan_tri[9] = {-9, 0, 0, 9, NAN, 0, 0, 9, 0}, inf_tri[9] = {-9, 0, 0, INFINITY, 1, 0, 0, 9, 0}, far_tri[9] = {-9, 0, 0, 3e18f, 1, 0, 0, 9, 0}, point[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+          odd.insert(odd.end(), nan_tri, nan_tri + 9); odd.insert(odd.end(), inf_tri, inf_tri + 9); odd.insert(odd.end(), far_tri, far_tri + 9); odd.insert(odd.end(), point, point + 9); }
+        bad += check_split("split: small triangles only", small, 0.3f, false);
+        bad += check_split("split: large among small", mixed, 0.3f, true);
+        bad += check_split("split: budget 0", mixed, 0.0f, false);
+        bad += check_split("split: tiny budget", mixed, 0.001f, true);
+        bad += check_split("split: budget 4", mixed, 4.0f, true);
+        bad += check_split("split: NaN, inf, huge, point", odd, 0.3f, true);
+        bad += check_split("split: nothing", {}, 0.3f, false);
+    }
     for (const char *name : {"fixture", "blob70k", "hall260k"}) {
         std::unique_ptr<ptm::Scene> s(ptm::Scene::create(name));
         std::vector<Aabb> boxes;
