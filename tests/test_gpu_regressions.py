@@ -239,3 +239,44 @@ def test_master_mirror_render_scale():
         assert lib.ptm_master_set_render_scale(h, 64, 36, 0.0) != 0
     finally:
         lib.ptm_master_destroy(h)
+
+
+def test_master_mirror_skybox_from_a_radiance_picture(tmp_path):
+    """SkyboxTexture (RayTracingMaster.cs:25, bound at :457) from a .hdr file, the format of the reference's asset: the
+    frame equals the oracle's with the decoded picture as its sky, and differs from the frame under the procedural sky."""
+    rng = np.random.default_rng(12)
+    H0, W0 = 32, 64
+    rgbe = np.empty((H0, W0, 4), np.uint8)
+    rgbe[:, :, :3] = rng.integers(40, 256, (H0, W0, 3))
+    rgbe[:, :, 3] = rng.integers(126, 131, (H0, W0))
+    path = tmp_path / "sky.hdr"
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {H0} +X {W0}\n".encode() + rgbe.tobytes())     # flat scanlines
+    sky = pa.load_hdr(path)
+    assert sky.shape == (H0, W0, 4) and sky[..., :3].max() > 2.0
+    lib = _ffi.ptmaster(); pt = _ffi.ptrace()
+    h = C.c_void_p()
+    assert lib.ptm_master_create(0, C.byref(h)) == 0, lib.ptm_master_error(h)
+    try:
+        s = pa.Scene("fixture")
+        assert lib.ptm_master_load_scene(h, s.handle, 64, 32) == 0, lib.ptm_master_error(h)
+        lib.ptm_master_configure(h, 1, 1, 2, 4, 0, pa.PT_ACCUM_NONE, 4)
+        W, H = 64, 36
+        assert lib.ptm_master_set_render_scale(h, W, H, 1.0) == 0
+        frames = []
+        for use_file in (False, True):
+            if use_file:
+                assert lib.ptm_master_set_sky_hdr(h, str(path).encode(), 2048) == 0, lib.ptm_master_error(h)
+            p = pa.PtFrameParams()
+            lib.ptm_master_peek_params(h, C.byref(p))
+            assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
+            got = np.empty((H, W, 4), np.float32)
+            assert pt.pt_read_result(lib.ptm_master_context(h), got.ctypes.data) == 0
+            c, _, _ = po.Oracle.from_scene(s, sky if use_file else pa.procedural_sky(64, 32), accel=False).render(p, W, H, threads=4)
+            assert _same(got, c), use_file
+            frames.append(got)
+        assert not _same(frames[0], frames[1])
+        assert lib.ptm_master_set_sky_hdr(h, str(tmp_path / "absent.hdr").encode(), 2048) != 0
+        assert b"cannot open" in lib.ptm_master_error(h)
+    finally:
+        lib.ptm_master_destroy(h)
