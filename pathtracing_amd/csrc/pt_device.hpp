@@ -27,6 +27,14 @@ struct SceneDev {
     int32_t sky_w, sky_h;
     int32_t n_nodes, n_prims, n_spheres;
     int32_t n_nodes4;          // four-wide nodes (the stride between the node arrays of a PT_NODES_SOA build)
+    // two-level scenes (instances): NULL / 0 when every mesh object is flattened into world-space records
+    const float4 *inst;        // 8 x float4 per instance: rows 0..2 of localToWorld (x = row . (v, 1)), rows 0..2 of its inverse,
+                               // (bits(root node of the mesh's tree), bits(id of the instance's first triangle), bits(mesh object index), 0), spare
+    const int4 *objects;       // per mesh object: (first triangle in scene order, first index, 0, 0); one more entry holds the triangle total
+    const int32_t *indices;    // the scene's index buffer (RayTracingMaster.cs:107)
+    const float *vertices;     // object-space positions, 3 floats per vertex (:106)
+    const float *matrices;     // 16 floats per mesh object (:105)
+    int32_t n_inst;
 };
 
 // How far outside a triangle the Moeller-Trumbore arithmetic (SH:192-230) can still report a hit.  Its barycentric
@@ -123,6 +131,10 @@ constexpr int kStackOverflow = 80;     // further entries in a global buffer.  C
                                        // collapse can push past 92 - the host measures each tree's worst case (BvhResult::stack_need4)
                                        // and walks the two-child tree instead when it does not fit
 constexpr int kDoneNode = (int)0x80000000;   // traversal state "stack empty: ray finished"
+// Two-level scenes: a leaf link with this bit set in its complement names an instance (~link = kInstanceBit | instance)
+// instead of primitive records, and kExitInstance on the stack marks where a ray leaves the instance it is in.
+constexpr uint32_t kInstanceBit = 0x40000000u;
+constexpr int kExitInstance = (int)0x80000007;   // between the lane states below and the smallest leaf link
 
 __device__ __forceinline__ float as_f(int32_t i) { return __int_as_float(i); }
 __device__ __forceinline__ int32_t as_i(float f) { return __float_as_int(f); }
@@ -351,6 +363,119 @@ __device__ __forceinline__ int32_t leaf_step(const SceneDev &sc, int32_t node, f
     return sp ? stack_pop(st, sp) : kDoneNode;
 }
 
+// ---- two-level scenes: mesh objects that share a mesh keep one tree over the mesh's object-space triangles, and the
+// top-level tree holds one box per such object ("instance").  The ray is taken into object space for the walk through
+// the boxes only (conservative: the mesh's boxes are padded for the rounding of that transform); every triangle test
+// runs in world space on vertices transformed as RayTracingShader.compute:238-240 transforms them, so the hit found
+// is bit for bit the one of the flattened scene.
+
+// row . (v, 1) in pt_mul_point's order of operations (include/ptrace_fmath.h)
+__device__ __forceinline__ f3 rows_point(float4 r0, float4 r1, float4 r2, f3 v)
+{
+    f3 r;
+    r.x = pt_fma(r0.z, v.z, pt_fma(r0.y, v.y, r0.x * v.x)) + r0.w;
+    r.y = pt_fma(r1.z, v.z, pt_fma(r1.y, v.y, r1.x * v.x)) + r1.w;
+    r.z = pt_fma(r2.z, v.z, pt_fma(r2.y, v.y, r2.x * v.x)) + r2.w;
+    return r;
+}
+__device__ __forceinline__ f3 rows_dir(float4 r0, float4 r1, float4 r2, f3 v)
+{
+    f3 r;
+    r.x = pt_fma(r0.z, v.z, pt_fma(r0.y, v.y, r0.x * v.x));
+    r.y = pt_fma(r1.z, v.z, pt_fma(r1.y, v.y, r1.x * v.x));
+    r.z = pt_fma(r2.z, v.z, pt_fma(r2.y, v.y, r2.x * v.x));
+    return r;
+}
+
+// The slab constants of the ray as instance `inst` sees it.  The ray's parameter is the same in both spaces.
+__device__ __forceinline__ RaySlabs instance_slabs(const SceneDev &sc, int inst, f3 o, f3 d)
+{
+    const float4 *q = sc.inst + (size_t)inst * 8 + 3;
+    const float4 i0 = q[0], i1 = q[1], i2 = q[2];
+    return ray_slabs(rows_point(i0, i1, i2, o), rows_dir(i0, i1, i2, d));
+}
+
+// The two links only two-level scenes have, resolved as soon as a step returns them, so that they never cost a phase of
+// their own: an instance link (enter: the exit marker goes on the stack, the ray's slab constants become those of its
+// object-space image, the walk continues at the mesh's root, an inner node) and the exit marker (back to world space,
+// next stacked node).  `cur_inst` is the instance the ray is in (-1: top level), `r` its slab constants there.
+__device__ __forceinline__ bool is_instance_link(int32_t node) { return node < (int32_t)0xc0000000 && node > kExitInstance; }
+template <class ST>
+__device__ __forceinline__ void resolve_instance_links(const SceneDev &sc, int32_t &node, f3 o, f3 d, int &cur_inst, RaySlabs &r,
+                                                       const ST &st, int &sp)
+{
+    while (node == kExitInstance) {
+        cur_inst = -1;
+        r = ray_slabs(o, d);
+        node = sp ? stack_pop(st, sp) : kDoneNode;
+    }
+    if (is_instance_link(node)) {
+        cur_inst = (int)((uint32_t)~node & (kInstanceBit - 1u));
+        r = instance_slabs(sc, cur_inst, o, d);
+        stack_push(st, sp, kExitInstance);
+        node = as_i(sc.inst[(size_t)cur_inst * 8 + 6].x);
+    }
+}
+
+// leaf_step for two-level scenes.  At the top level a record of kind 2 stands for an instance whose box shares a leaf
+// with other records: its link is stacked.  Inside an instance the records hold object-space vertices; the test runs on
+// their world-space images.  For a hit inside an instance recbest = 0x80000000 | mesh object index.
+template <class ST>
+__device__ __forceinline__ int32_t leaf_step_inst(const SceneDev &sc, int32_t node, f3 o, f3 d, int &cur_inst, RaySlabs &r,
+                                                  float &tbest, int32_t &idbest, uint32_t &recbest, const ST &st, int &sp, uint32_t &n_prims)
+{
+    const uint32_t enc = (uint32_t)~node;
+    const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+    if (cur_inst < 0) {
+        for (uint32_t k = 0; k < count; k++) {
+            const float4 *p = sc.prims + (size_t)(first + k) * 3;
+            const float4 a = p[0], b = p[1], c = p[2];
+            if (as_i(b.w) == 2) stack_push(st, sp, (int32_t)~(kInstanceBit | (uint32_t)as_i(b.x)));
+            else intersect_record(a, b, c, first + k, o, d, tbest, idbest, recbest);
+        }
+    } else {
+        const float4 *q = sc.inst + (size_t)cur_inst * 8;
+        const float4 m0 = q[0], m1 = q[1], m2 = q[2], meta = q[6];
+        // as in leaf_step: two records per round trip, their words (and the matrix rows) all in flight together
+        for (uint32_t k = 0; k < count; k += 2) {
+            const bool two = k + 1 < count;
+            const float4 *p = sc.prims + (size_t)(first + k) * 3;
+            const float4 *p2 = two ? p + 3 : p;
+            const float4 a0 = p[0], b0 = p[1], c0 = p[2], a1 = p2[0], b1 = p2[1], c1 = p2[2];   // object-space vertices; a.w = triangle index within the mesh
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (h == 1 && !two) break;
+                const float4 a = h ? a1 : a0, b = h ? b1 : b0, c = h ? c1 : c0;
+                const f3 v0 = rows_point(m0, m1, m2, xyz(a)), v1 = rows_point(m0, m1, m2, xyz(b)), v2 = rows_point(m0, m1, m2, xyz(c));   // SH:238-240
+                const f3 e1 = pt_sub3(v1, v0), e2 = pt_sub3(v2, v0);
+                intersect_record(make_float4(v0.x, v0.y, v0.z, as_f(as_i(meta.y) + as_i(a.w))), make_float4(e1.x, e1.y, e1.z, 0.0f),
+                                 make_float4(e2.x, e2.y, e2.z, 0.0f), 0x80000000u | (uint32_t)as_i(meta.z), o, d, tbest, idbest, recbest);
+            }
+        }
+    }
+    n_prims += count;
+    int32_t next = sp ? stack_pop(st, sp) : kDoneNode;
+    resolve_instance_links(sc, next, o, d, cur_inst, r, st, sp);
+    return next;
+}
+
+// World-space edges of triangle `id` (a hit inside an instance of mesh object `obj`), from the reference's own buffers
+// (RayTracingShader.compute:236-240): what the flattened scene keeps in the primitive record.
+__device__ __forceinline__ void instanced_edges(const SceneDev &sc, int32_t id, int obj, f3 &e1, f3 &e2)
+{
+    const int4 ob = sc.objects[obj];
+    const int32_t *ix = sc.indices + ob.y + 3 * (id - 1 - sc.n_spheres - ob.x);
+    const float *m = sc.matrices + 16 * (size_t)obj;
+    float mm[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) mm[k] = m[k];
+    const float *pa = sc.vertices + 3 * (size_t)ix[0], *pb = sc.vertices + 3 * (size_t)ix[1], *pc = sc.vertices + 3 * (size_t)ix[2];
+    const f3 v0 = pt_mul_point(mm, pt_make3(pa[0], pa[1], pa[2]));
+    const f3 v1 = pt_mul_point(mm, pt_make3(pb[0], pb[1], pb[2]));
+    const f3 v2 = pt_mul_point(mm, pt_make3(pc[0], pc[1], pc[2]));
+    e1 = pt_sub3(v1, v0); e2 = pt_sub3(v2, v0);
+}
+
 // Closest hit over spheres and triangles through the BVH.  tbest/idbest come in
 // holding the ground-plane result (or +inf / -1).
 template <int WIDE, class ST>
@@ -358,9 +483,17 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
                                          uint32_t &recbest, const ST &st, uint32_t &n_nodes, uint32_t &n_prims)
 {
     if (sc.n_nodes == 0) return;
-    const RaySlabs r = ray_slabs(o, d);
+    RaySlabs r = ray_slabs(o, d);
     int sp = 0;
     int32_t node = 0;
+    if (sc.n_inst) {
+        int cur_inst = -1;
+        while (node != kDoneNode) {
+            if (node >= 0) { node = node_step<WIDE>(sc, node, r, tbest, st, sp); n_nodes++; resolve_instance_links(sc, node, o, d, cur_inst, r, st, sp); }
+            else node = leaf_step_inst(sc, node, o, d, cur_inst, r, tbest, idbest, recbest, st, sp, n_prims);
+        }
+        return;
+    }
     while (node != kDoneNode) {
         if (node >= 0) { node = node_step<WIDE>(sc, node, r, tbest, st, sp); n_nodes++; }
         else node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, n_prims);
@@ -466,7 +599,7 @@ __device__ __forceinline__ f3 sample_ggx(Rng &rs, f3 normal, f3 specular, float 
 // as the arithmetic allows (emission right after the material fetch, the material folded into one
 // weight before the hemisphere sampling) to keep few registers live across the sampling code.
 // MAT: mesh objects carry their own PtMaterial (SceneDev::mesh_mat), possibly with the GGX lobe.
-template <bool MAT = false>
+template <bool MAT = false, bool INST = false>
 __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f3 &energy, f3 &result, float fspp,
                                       float t, int32_t id, uint32_t rec, f3 &hit_pos)
 {
@@ -495,10 +628,19 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
             specular = xyz(m2);
             emitted = xyz(m3);
         } else {                                        // SH:249-253
-            float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
-            nraw = pt_cross3(xyz(b), xyz(c));
+            int obj;
+            if (INST && (rec & 0x80000000u)) {
+                obj = (int)(rec & 0x7fffffffu);
+                f3 e1, e2;
+                instanced_edges(sc, id, obj, e1, e2);
+                nraw = pt_cross3(e1, e2);
+            } else {
+                float4 b = sc.prims[rec * 3 + 1], c = sc.prims[rec * 3 + 2];
+                nraw = pt_cross3(xyz(b), xyz(c));
+                obj = as_i(c.w);
+            }
             if (MAT && sc.mesh_mat) {
-                const float4 *m = sc.mesh_mat + (size_t)as_i(c.w) * 3;
+                const float4 *m = sc.mesh_mat + (size_t)obj * 3;
                 const float4 m0 = m[0], m1 = m[1], m2 = m[2];
                 albedo = xyz(m0); smoothness = m0.w;
                 specular = xyz(m1); lobe = as_i(m1.w);
@@ -609,11 +751,13 @@ __device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, i
     return x < a.tx0 + a.tw && y < a.ty0 + a.th;
 }
 
-// The length of a pixel's first path goes to its block's cost counter.
-__device__ __forceinline__ void note_cost(const RenderArgs &a, int pix_x, int pix_y, int path_length)
+// What a pixel's first path cost (node visits + primitive tests, or 16 per ray where those are not at hand) goes to its
+// block's cost counter.
+constexpr int kFirstSample = 1 << 19;
+__device__ __forceinline__ void note_cost(const RenderArgs &a, int pix_x, int pix_y, int work)
 {
     if (a.block_cost)
-        atomicAdd(a.block_cost + (uint32_t)((pix_y - a.ty0) >> 3) * (uint32_t)a.tiles_x + (uint32_t)((pix_x - a.tx0) >> 3), (uint32_t)path_length);
+        atomicAdd(a.block_cost + (uint32_t)((pix_y - a.ty0) >> 3) * (uint32_t)a.tiles_x + (uint32_t)((pix_x - a.tx0) >> 3), (uint32_t)work);
 }
 
 // dot(_Pixel, float2(12.9898, 78.233)) with _Pixel = id.xy * 2 (SH:831, SH:52)
@@ -849,7 +993,8 @@ __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && n
 // kernel's occupancy, down, and costs no memory traffic.
 //   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, t of the primary hit)
 //   ls2 = (pixel x | y << 16, sample | bounce << 20, primary record, primary id)   ls3 = (rays, nodes, prims, paths) counters
-template <int WIDE, bool MAT>
+//   (sample: below 2^19; in a pixel's first sample kFirstSample | cost of the pixel so far)
+template <int WIDE, bool MAT, bool INST = false>
 __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 {
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
@@ -869,6 +1014,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
     RaySlabs rsl = {0, 0, 0, 0, 0, 0};
     float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
     int32_t node = kIdleNode; int sp = 0;
+    int cur_inst = -1;                    // INST: the instance the ray is walking through, -1 at the top level
     uint32_t ray_work = 0;                // nodes | prims << 16 of the current ray
     int shard = (int)(blockIdx.x % (uint32_t)a.n_shards);   // wave-uniform: which part of the frame this wave draws pixels from
     bool frame_drained = false;
@@ -876,6 +1022,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #ifdef PT_PROFILE_PHASES
     uint32_t ph_rounds[3] = {0, 0, 0}, ph_lanes[3] = {0, 0, 0};   // wave-uniform
     unsigned long long ph_cyc[3] = {0, 0, 0}, ph_t0 = clock64(); int ph_cur = -1;
+    const unsigned long long ph_wall0 = wall_clock64();
 #define PH_SWITCH(k) { unsigned long long t_ = clock64(); if (ph_cur >= 0) ph_cyc[ph_cur] += t_ - ph_t0; ph_t0 = t_; ph_cur = (k); }
 #endif
 
@@ -895,7 +1042,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // LDS so that the shading code has those registers (the compiler cannot know they are idle).
             {
                 float *sv = lds_save + threadIdx.x;
-                sv[0 * kBlock] = as_f(node); sv[1 * kBlock] = as_f(sp); sv[2 * kBlock] = as_f((int32_t)ray_work);
+                sv[0 * kBlock] = as_f(node); sv[1 * kBlock] = as_f(INST ? sp | ((cur_inst + 1) << 8) : sp); sv[2 * kBlock] = as_f((int32_t)ray_work);
             }
             const bool was_done = node == kDoneNode, was_idle = node == kIdleNode;
             bool new_ray = false, finished = false, no_more = false;
@@ -906,11 +1053,16 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             if (was_done) {
                 const int4 px = *ls2;
                 const int pix_x = px.x & 0xffff, pix_y = px.x >> 16;
-                int sample = px.y & 0xfffff, bounce = (int)((uint32_t)px.y >> 20), primary_id = px.w;
+                // during a pixel's first sample the sample field holds kFirstSample | the node visits and primitive tests of the
+                // pixel so far: what the pixel costs, for the next dispatch's block order
+                const bool first_sample = (px.y & kFirstSample) != 0;
+                int sample = first_sample ? 0 : (px.y & (kFirstSample - 1)), bounce = (int)((uint32_t)px.y >> 20), primary_id = px.w;
+                uint32_t pix_work = first_sample ? (uint32_t)(px.y & (kFirstSample - 1)) : 0u;
                 uint32_t primary_rec = (uint32_t)px.z;
                 {
                     const uint32_t rw = (uint32_t)as_i(lds_save[threadIdx.x + 2 * kBlock]);
                     cnt.y += (int)(rw & 0xffffu); cnt.z += (int)(rw >> 16);
+                    pix_work = min(pix_work + (rw & 0xffffu) + (rw >> 16), (uint32_t)kFirstSample - 1u);
                 }
                 if (a.depth == 1) {                                   // SH:799-809
                     size_t p = (size_t)pix_y * a.W + pix_x;
@@ -943,7 +1095,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         }
                     }
                     if (!from_history) {
-                    shade<MAT>(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
+                    shade<MAT, INST>(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
                     bool path_done;
                     if (bounce == 0) {
                         primary_id = idbest;
@@ -956,7 +1108,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     bounce++;
                     new_ray = true;
                     if (path_done) {
-                        if (sample == 0) note_cost(a, pix_x, pix_y, bounce);
+                        if (sample == 0) note_cost(a, pix_x, pix_y, (int)pix_work);
                         sample++;
                         if (sample < a.spp) {                          // next sample of the same pixel, SH:839
                             bounce = 0;
@@ -997,7 +1149,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     if (new_ray) {
                         *ls0 = make_float4(energy.x, energy.y, energy.z, rs.seed);
                         *ls1 = make_float4(result.x, result.y, result.z, t_primary);
-                        *ls2 = make_int4(px.x, sample | (bounce << 20), (int)primary_rec, primary_id);
+                        *ls2 = make_int4(px.x, (sample == 0 ? (int)(kFirstSample | pix_work) : sample) | (bounce << 20), (int)primary_rec, primary_id);
                     }
                     }   // !from_history
                 }
@@ -1032,7 +1184,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         if (item_pixel(a, item, x, y) && !(MAT && a.skip_t && !(a.skip_t[(size_t)y * a.W + x] < PT_INF))) {
                             *ls0 = make_float4(1.0f, 1.0f, 1.0f, a.seed);
                             *ls1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            *ls2 = make_int4(x | (y << 16), 0, 0, -1);   // sample 0, bounce 0, no primary hit yet
+                            *ls2 = make_int4(x | (y << 16), kFirstSample, 0, -1);   // first sample, no work yet, bounce 0, no primary hit yet
                             camera_ray<MAT>(a, x, y, o, d);
                             cnt.w++;
                             new_ray = true;
@@ -1044,6 +1196,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             {
                 const float *sv = lds_save + threadIdx.x;
                 node = as_i(sv[0 * kBlock]); sp = as_i(sv[1 * kBlock]); ray_work = (uint32_t)as_i(sv[2 * kBlock]);
+                if (INST) { cur_inst = (sp >> 8) - 1; sp &= 0xff; }
             }
             if (no_more) node = kDeadNode;
             else if (finished && !new_ray) node = kIdleNode;   // pixel done, its replacement lay outside the tile
@@ -1051,6 +1204,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
                 sp = 0;
+                cur_inst = -1;
                 node = sc.n_nodes ? 0 : kDoneNode;
                 ray_work = 0;
                 cnt.x++;
@@ -1062,7 +1216,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             }
             // The slab constants are not kept across the shade phase: every lane computes them here, the lanes that kept
             // their ray getting the values they had (the wave runs this code for the new rays anyway).
-            rsl = ray_slabs(o, d);
+            rsl = INST && cur_inst >= 0 ? instance_slabs(sc, cur_inst, o, d) : ray_slabs(o, d);
             if (waiting) *ls3 = cnt;
             continue;
         }
@@ -1075,7 +1229,10 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // keep stepping while enough lanes hold an inner node; the other lanes' states cannot change
             // meanwhile, so only that one count is re-evaluated
             for (;;) {
-                if (node >= 0) { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++; }
+                if (node >= 0) {
+                    node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++;
+                    if (INST) resolve_instance_links(sc, node, o, d, cur_inst, rsl, st, sp);
+                }
                 const int still = __popcll(__ballot(node >= 0));
 #ifdef PT_PROFILE_PHASES
                 if (still >= a.vote_node) { ph_rounds[1]++; ph_lanes[1] += still; }
@@ -1091,7 +1248,8 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #endif
         if (leaf) {
             uint32_t np = 0;
-            node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, np);
+            if (INST) node = leaf_step_inst(sc, node, o, d, cur_inst, rsl, tbest, idbest, recbest, st, sp, np);
+            else node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, np);
             ray_work += np << 16;
         }
     }
@@ -1108,6 +1266,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 5 + 2 * k], (unsigned long long)ph_lanes[k]);
             atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 10 + k], ph_cyc[k]);
         }
+    if (lane == 0 && a.stats) {      // how long this wave lived, in ticks of the constant 100 MHz counter: sum and maximum
+        const unsigned long long life = wall_clock64() - ph_wall0;
+        atomicAdd(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 13], life);
+        atomicMax(&a.stats[(blockIdx.x % kStatsShards) * kStatsStride + 14], life);
+    }
 #endif
 }
 
@@ -1115,6 +1278,15 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #undef ls1
 #undef ls2
 #undef ls3
+
+// The extended kernel for two-level scenes (instances; leaf_step_inst).
+#ifndef PT_INST_WAVES
+#define PT_INST_WAVES 4   // 128 VGPRs: at 5 waves (96) the kernel spills 81 registers and runs 10 % slower
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_INST_WAVES))) void path_sched_inst_kernel(const RenderArgs a)
+{
+    path_sched_body<4, true, true>(a);
+}
 
 // Five waves per SIMD (96 VGPRs): the few values that do not fit are kernel constants spilled once at entry and read back
 // in the shade phase; the node and leaf loops hold no scratch access.  Measured against four waves (128 VGPRs, nothing
@@ -1135,13 +1307,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 
 // order[] = the blocks by falling cost (a counting sort on the clamped cost; ties in no particular order: any
 // permutation renders the same image), and the counters back to zero for the frame that is about to start.
-constexpr int kOrderThreads = 1024, kOrderBins = 2048;
+constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderShift = 3;   // a block's 64 first paths cost some thousands of steps: bins of 8
 __global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *cost, uint32_t *order, uint32_t n_blocks)
 {
     __shared__ uint32_t bin[kOrderBins];
     for (int i = threadIdx.x; i < kOrderBins; i += kOrderThreads) bin[i] = 0;
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) atomicAdd(&bin[min(cost[b], (uint32_t)kOrderBins - 1u)], 1u);
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) atomicAdd(&bin[min(cost[b] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {                 // first rank of every bin, most expensive bin first
         uint32_t run = 0;
@@ -1149,7 +1321,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *c
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) {
-        order[atomicAdd(&bin[min(cost[b], (uint32_t)kOrderBins - 1u)], 1u)] = b;
+        order[atomicAdd(&bin[min(cost[b] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u)] = b;
         cost[b] = 0;
     }
 }
@@ -1181,11 +1353,29 @@ __global__ __launch_bounds__(kBlock) void trace_rays_brute_kernel(SceneDev sc, c
     f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);
     float t = PT_INF; int32_t id = -1;
     intersect_ground_plane(o, d, t, id);
+    uint32_t rec = 0;
+    // intersect_record keeps the (t, id)-smallest hit, which is what the strict comparison keeps when the primitives
+    // come in id order - so the order of the two loops below does not matter
     for (int k = 0; k < sc.n_prims; k++) {
-        // a fresh (+inf, max id) candidate, so that only a strict improvement over `t` is accepted
-        float tc = PT_INF; int32_t ic = 0x7fffffff; uint32_t rc = 0;
-        intersect_prim(sc.prims, by_id[k], o, d, tc, ic, rc);
-        if (tc < t) { t = tc; id = ic; }
+        const uint32_t slot = by_id[k];
+        if (slot != 0xffffffffu) intersect_prim(sc.prims, slot, o, d, t, id, rec);      // 0xffffffff: a triangle of an instance, below
+    }
+    for (int ii = 0; ii < sc.n_inst; ii++) {
+        const float4 meta = sc.inst[(size_t)ii * 8 + 6];
+        const int obj = as_i(meta.z), id0 = as_i(meta.y);
+        const int4 ob = sc.objects[obj];
+        const int n_tris = sc.objects[obj + 1].x - ob.x;
+        const float *m = sc.matrices + 16 * (size_t)obj;
+        for (int k = 0; k < n_tris; k++) {
+            const int32_t *ix = sc.indices + ob.y + 3 * k;
+            const float *pa = sc.vertices + 3 * (size_t)ix[0], *pb = sc.vertices + 3 * (size_t)ix[1], *pc = sc.vertices + 3 * (size_t)ix[2];
+            const f3 v0 = pt_mul_point(m, pt_make3(pa[0], pa[1], pa[2]));      // SH:238-240
+            const f3 v1 = pt_mul_point(m, pt_make3(pb[0], pb[1], pb[2]));
+            const f3 v2 = pt_mul_point(m, pt_make3(pc[0], pc[1], pc[2]));
+            const f3 e1 = pt_sub3(v1, v0), e2 = pt_sub3(v2, v0);
+            intersect_record(make_float4(v0.x, v0.y, v0.z, as_f(id0 + k)), make_float4(e1.x, e1.y, e1.z, 0.0f), make_float4(e2.x, e2.y, e2.z, 0.0f),
+                             0, o, d, t, id, rec);
+        }
     }
     ids[i] = id; ts[i] = t;
 }

@@ -290,7 +290,7 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
                     bounce++;
                     new_ray = true;
                     if (path_done) {
-                        if (sample == 0) note_cost(a, pix_x, pix_y, bounce);
+                        if (sample == 0) note_cost(a, pix_x, pix_y, 16 * bounce);
                         sample++;
                         if (sample < a.spp) {                          // next sample of the same pixel, SH:839
                             bounce = 0;

@@ -77,6 +77,14 @@ struct pt_context {
     float split_budget = 0.3f;        // option "split_percent": additional references, per triangle of the scene, the build may spend on large triangles
     float *d_slot_clip = nullptr;     // per slot, the unpadded box of its reference (only when some triangle was split)
     float *d_build_matrices = nullptr;   // the matrices those boxes were cut under
+    // two-level scenes: mesh objects that share a mesh and are placed by a rotation, a uniform scale and a translation keep
+    // one tree over the mesh's object-space triangles; the top-level tree holds a box per such object
+    int instancing = 0;               // option "instancing"
+    int n_inst = 0;                   // instances in the current build (0: everything flattened)
+    bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
+    float4 *d_inst = nullptr;         // SceneDev::inst
+    int4 *d_objects = nullptr;        // SceneDev::objects
+    int32_t *d_indices = nullptr;     // SceneDev::indices
 
     // targets
     int W = 0, H = 0;
@@ -104,6 +112,7 @@ struct pt_context {
     int node_vote = 8;
     int vote_shade = 44, vote_node = 16;
     int sched_blocks_per_cu = 0, sched_ext_blocks_per_cu = 0;   // resident blocks per CU of path_sched_kernel / path_sched_mat_kernel
+    int sched_inst_blocks_per_cu = 0;                           // and of path_sched_inst_kernel
     int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
     int reuse_primary = 0;                 // option "reuse_primary_hit"
     int backend = 0;                       // 0 = path_sched_kernel (one ray per lane), 1 = wavefront stages, 2 = path_pool_kernel (ray pool per wave)
@@ -239,6 +248,97 @@ int upload(pt_context *ctx, T *&dst, const void *src, size_t bytes)
     return PT_OK;
 }
 
+static inline void box_reset_inf(Aabb &b)
+{
+    for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+}
+
+// ---- two-level scenes ----------------------------------------------------------------------------------------------
+// Mesh objects with the same index range are instances of one mesh (that is how RebuildMeshObjectBuffers lays out objects
+// that share a sharedMesh, RayTracingMaster.cs:387-408).  A group of two or more of them gets one tree over the mesh's
+// object-space triangles if every member is placed by a similarity: localToWorld = rotation (or mirror) * uniform
+// scale + translation, finite, scale within [1e-3, 1e3].  Under a similarity a box padded by p in object space holds
+// everything within p * scale of the triangle in world space, whichever way the object is turned; shears and uneven
+// scales have no such bound and stay flattened, as do meshes of fewer than kMinInstanceTris triangles.
+struct MeshGroup {
+    int32_t indices_offset = 0, indices_count = 0;
+    std::vector<int> objects;      // members, in scene order
+    double scale_min = 0.0;        // smallest uniform scale among them
+    double inv_norm = 0.0;         // largest infinity norm of an inverse linear part
+};
+constexpr int kMinInstanceTris = 64;      // PTRACE_INSTANCE_MIN_TRIS lowers it (tests with tiny meshes)
+
+// The uniform scale of a similarity, or 0.
+double similarity_scale(const float *m)
+{
+    double a[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) {
+            const float v = m[j * 4 + i];
+            if (!(std::fabs(v) < 1e6f)) return 0.0;          // NaN, infinite or absurd
+            if (j < 3) a[i][j] = v;
+        }
+    double g[3][3], s2 = 0.0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { g[i][j] = a[0][i] * a[0][j] + a[1][i] * a[1][j] + a[2][i] * a[2][j]; if (i == j) s2 += g[i][j] / 3.0; }
+    if (!(s2 > 1e-6 && s2 < 1e6)) return 0.0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            if (std::fabs(g[i][j] - (i == j ? s2 : 0.0)) > 1e-4 * s2) return 0.0;
+    return std::sqrt(s2);
+}
+
+// Inverse of the affine map x -> A x + b held in rows 0..2 of m (column-major 4x4), as rows (Ainv | -Ainv b).
+void affine_inverse_rows(const float *m, double inv[3][4])
+{
+    double a[3][3], b[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) a[i][j] = m[j * 4 + i]; b[i] = m[12 + i]; }
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    const double c[3][3] = {{a[1][1] * a[2][2] - a[1][2] * a[2][1], a[0][2] * a[2][1] - a[0][1] * a[2][2], a[0][1] * a[1][2] - a[0][2] * a[1][1]},
+                            {a[1][2] * a[2][0] - a[1][0] * a[2][2], a[0][0] * a[2][2] - a[0][2] * a[2][0], a[0][2] * a[1][0] - a[0][0] * a[1][2]},
+                            {a[1][0] * a[2][1] - a[1][1] * a[2][0], a[0][1] * a[2][0] - a[0][0] * a[2][1], a[0][0] * a[1][1] - a[0][1] * a[1][0]}};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) inv[i][j] = c[i][j] / det;
+        inv[i][3] = -(inv[i][0] * b[0] + inv[i][1] * b[1] + inv[i][2] * b[2]);
+    }
+}
+
+std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, std::vector<int> &obj_group)
+{
+    std::vector<MeshGroup> groups;
+    int min_tris = kMinInstanceTris;
+    if (const char *env = std::getenv("PTRACE_INSTANCE_MIN_TRIS")) min_tris = std::max(1, std::atoi(env));
+    std::vector<std::pair<std::pair<int32_t, int32_t>, int>> keyed;      // ((offset, count), object)
+    for (size_t o = 0; o < objects.size(); o++)
+        if (objects[o].indices_count / 3 >= min_tris && objects[o].indices_offset >= 0) keyed.push_back({{objects[o].indices_offset, objects[o].indices_count}, (int)o});
+    std::sort(keyed.begin(), keyed.end());
+    for (size_t i = 0; i < keyed.size();) {
+        size_t j = i;
+        MeshGroup g;
+        g.indices_offset = keyed[i].first.first; g.indices_count = keyed[i].first.second;
+        g.scale_min = 1e30;
+        for (; j < keyed.size() && keyed[j].first == keyed[i].first; j++) {
+            const float *m = objects[(size_t)keyed[j].second].local_to_world;
+            const double sc = similarity_scale(m);
+            if (!(sc >= 1e-3 && sc <= 1e3)) continue;
+            double inv[3][4];
+            affine_inverse_rows(m, inv);
+            double norm = 0.0;
+            for (int r = 0; r < 3; r++) norm = std::max(norm, std::fabs(inv[r][0]) + std::fabs(inv[r][1]) + std::fabs(inv[r][2]));
+            if (!std::isfinite(norm)) continue;
+            g.objects.push_back(keyed[j].second);
+            g.scale_min = std::min(g.scale_min, sc); g.inv_norm = std::max(g.inv_norm, norm);
+        }
+        if (g.objects.size() >= 2) {
+            for (int o : g.objects) obj_group[(size_t)o] = (int)groups.size();
+            groups.push_back(std::move(g));
+        }
+        i = j;
+    }
+    return groups;
+}
+
 // Flatten meshes to world space (RayTracingShader.compute:236-240 applied once
 // instead of per ray), box every primitive, build the BVH, upload.
 int rebuild_scene(pt_context *ctx)
@@ -246,18 +346,41 @@ int rebuild_scene(pt_context *ctx)
     auto t0 = std::chrono::steady_clock::now();
     const int nS = (int)ctx->spheres.size();
     struct Tri { pt_f3 v0, v1, v2; };
-    std::vector<Tri> tris;
-    std::vector<int32_t> tri_object;
+    std::vector<Tri> tris;                 // the triangles kept as world-space records ("flattened")
+    std::vector<int32_t> tri_object;       // their mesh object
+    std::vector<uint32_t> tri_gid;         // and their index among all triangles of the scene in the reference's visiting order
     size_t nt = 0;
-    for (const PtMeshObject &mo : ctx->objects) nt += (size_t)std::max(0, mo.indices_count) / 3;
-    tris.reserve(nt); tri_object.reserve(nt);
+    std::vector<uint32_t> obj_first_tri(ctx->objects.size() + 1, 0);
+    for (size_t oi = 0; oi < ctx->objects.size(); oi++) {
+        obj_first_tri[oi] = (uint32_t)nt;
+        nt += (size_t)std::max(0, ctx->objects[oi].indices_count) / 3;
+    }
+    obj_first_tri[ctx->objects.size()] = (uint32_t)nt;
+    // ---- which mesh objects become instances of a shared tree
+    std::vector<int> obj_group(ctx->objects.size(), -1);
+    std::vector<MeshGroup> groups;
+#ifndef PT_NODES_SOA
+    if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, obj_group);
+#endif
+    ctx->flatten_once = false;
+    tris.reserve(nt); tri_object.reserve(nt); tri_gid.reserve(nt);
     ctx->object_box.assign(ctx->objects.size(), Aabb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}});
     for (size_t oi = 0; oi < ctx->objects.size(); oi++) {
         const PtMeshObject &mo = ctx->objects[oi];
         const int32_t end = mo.indices_offset + mo.indices_count;
         Aabb &ob = ctx->object_box[oi];
-        for (int32_t i = mo.indices_offset; i + 2 < end; i += 3) {
+        uint32_t gid = obj_first_tri[oi];
+        for (int32_t i = mo.indices_offset; i + 2 < end; i += 3, gid++) {
+            if (obj_group[oi] >= 0) {      // instanced: only the object-space bounds are needed here
+                for (int c = 0; c < 3; c++) {
+                    const float *v = &ctx->vertices[3 * (size_t)ctx->indices[i + c]];
+                    for (int k = 0; k < 3; k++)
+                        if (std::fabs(v[k]) < kHugeCoord) { ob.lo[k] = std::min(ob.lo[k], v[k]); ob.hi[k] = std::max(ob.hi[k], v[k]); }
+                }
+                continue;
+            }
             tri_object.push_back((int32_t)oi);
+            tri_gid.push_back(gid);
             const float *a = &ctx->vertices[3 * (size_t)ctx->indices[i]];
             const float *b = &ctx->vertices[3 * (size_t)ctx->indices[i + 1]];
             const float *c = &ctx->vertices[3 * (size_t)ctx->indices[i + 2]];
@@ -271,8 +394,9 @@ int rebuild_scene(pt_context *ctx)
             tris.push_back(t);
         }
     }
-    const size_t nP = (size_t)nS + tris.size();
-    if (nP >= (1u << 28)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^28 primitives");
+    const size_t nP = (size_t)nS + tris.size();        // primitives with a world-space record
+    const size_t nIds = (size_t)nS + nt;               // primitives of the scene (ids 1 .. nIds)
+    if (nIds >= (1u << 27)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^27 primitives");
 
     std::vector<Aabb> boxes(nP);
     float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -294,6 +418,17 @@ int rebuild_scene(pt_context *ctx)
             if (std::fabs(boxes[i].lo[k]) < kHugeCoord) slo[k] = std::min(slo[k], boxes[i].lo[k]);
             if (std::fabs(boxes[i].hi[k]) < kHugeCoord) shi[k] = std::max(shi[k], boxes[i].hi[k]);
         }
+    for (size_t oi = 0; oi < ctx->objects.size(); oi++) {       // instanced objects: the corners of their object-space bounds
+        const Aabb &ob = ctx->object_box[oi];
+        if (obj_group[oi] < 0 || !(ob.lo[0] <= ob.hi[0])) continue;
+        for (int corner = 0; corner < 8; corner++) {
+            const pt_f3 w = pt_mul_point(ctx->objects[oi].local_to_world, pt_make3((corner & 1) ? ob.hi[0] : ob.lo[0], (corner & 2) ? ob.hi[1] : ob.lo[1],
+                                                                                   (corner & 4) ? ob.hi[2] : ob.lo[2]));
+            const float wc[3] = {w.x, w.y, w.z};
+            for (int k = 0; k < 3; k++)
+                if (std::fabs(wc[k]) < kHugeCoord) { slo[k] = std::min(slo[k], wc[k]); shi[k] = std::max(shi[k], wc[k]); }
+        }
+    }
     // Pad every box: the intersection tests accept hits a few ulps outside the exact primitive.
     float diag = 0.0f;
     if (nP) diag = std::sqrt((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) +
@@ -361,15 +496,101 @@ int rebuild_scene(pt_context *ctx)
     float ct = 1.0f;
     if (const char *env = std::getenv("PTRACE_SAH_CT")) ct = (float)std::atof(env);
     auto t_prep = std::chrono::steady_clock::now();
+
+    // ---- two-level scenes: one tree per shared mesh over its object-space triangles, one top-level reference per instance
+    struct MeshTree { BvhResult bvh; std::vector<float4> recs; Aabb root; };
+    std::vector<MeshTree> mesh_trees(groups.size());
+    std::vector<int> inst_object;          // instance -> mesh object
+    int blas_stack_need = 0;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        const MeshGroup &g = groups[gi];
+        MeshTree &mt = mesh_trees[gi];
+        const size_t n = (size_t)g.indices_count / 3;
+        // How far, in object space, the ray's point at the hit's parameter can lie from the object-space triangle when the
+        // world-space test accepts the hit: the world padding of the flattened tree, the rounding of the world vertices and
+        // of the ray's transform (coordinates up to `coord`, a few ulps each), all taken through the inverse map.
+        float coord = reach;
+        for (int k = 0; k < 3; k++) coord = std::max(coord, std::max(std::fabs(ctx->scene_lo[k]), std::fabs(ctx->scene_hi[k])) + reach);
+        const float pad_o = (float)(g.inv_norm * 1.25 * ((double)pad + 4.8e-7 * (3.0 * coord + reach)));
+        const float reach_o = (float)(reach / g.scale_min);
+        std::vector<Aabb> ob(n);
+        box_reset_inf(mt.root);
+        for (size_t t = 0; t < n; t++) {
+            const int32_t *ix = &ctx->indices[(size_t)g.indices_offset + 3 * t];
+            const float *a = &ctx->vertices[3 * (size_t)ix[0]], *b = &ctx->vertices[3 * (size_t)ix[1]], *c = &ctx->vertices[3 * (size_t)ix[2]];
+            float own = 2.0f * triangle_fuzz(pt_make3(b[0] - a[0], b[1] - a[1], b[2] - a[2]), pt_make3(c[0] - a[0], c[1] - a[1], c[2] - a[2]), reach_o);
+            if (!(own < kHugeCoord)) own = kHugeCoord;
+            for (int k = 0; k < 3; k++) {
+                const float l = std::min(a[k], std::min(b[k], c[k])), h = std::max(a[k], std::max(b[k], c[k]));
+                const float rel = 4e-7f * std::max(std::fabs(l), std::fabs(h));
+                const float pp = std::max(pad_o, own);
+                if (!(std::fabs(l) + pp < kHugeCoord) || !(std::fabs(h) + pp < kHugeCoord)) { ob[t].lo[k] = -kHugeCoord; ob[t].hi[k] = kHugeCoord; }
+                else { ob[t].lo[k] = l - pp - rel; ob[t].hi[k] = h + pp + rel; }
+                mt.root.lo[k] = std::min(mt.root.lo[k], ob[t].lo[k]); mt.root.hi[k] = std::max(mt.root.hi[k], ob[t].hi[k]);
+            }
+        }
+        mt.bvh = build_bvh(ob, leaf_size, 0, ct);
+        blas_stack_need = std::max(blas_stack_need, mt.bvh.stack_need4);
+        mt.recs.resize(n * 3);
+        for (size_t slot = 0; slot < n; slot++) {
+            const uint32_t t = mt.bvh.order[slot];
+            const int32_t *ix = &ctx->indices[(size_t)g.indices_offset + 3 * t];
+            const float *a = &ctx->vertices[3 * (size_t)ix[0]], *b = &ctx->vertices[3 * (size_t)ix[1]], *c = &ctx->vertices[3 * (size_t)ix[2]];
+            float tf; const int32_t ti = (int32_t)t; std::memcpy(&tf, &ti, 4);
+            mt.recs[slot * 3 + 0] = make_float4(a[0], a[1], a[2], tf);
+            mt.recs[slot * 3 + 1] = make_float4(b[0], b[1], b[2], 0.0f);
+            mt.recs[slot * 3 + 2] = make_float4(c[0], c[1], c[2], 0.0f);
+        }
+        // a top-level reference per member: the world box of the mesh's root box under the member's matrix
+        for (int o : g.objects) {
+            const float *m = ctx->objects[(size_t)o].local_to_world;
+            Aabb wb; box_reset_inf(wb);
+            for (int corner = 0; corner < 8; corner++) {
+                const double v[3] = {(corner & 1) ? mt.root.hi[0] : mt.root.lo[0], (corner & 2) ? mt.root.hi[1] : mt.root.lo[1], (corner & 4) ? mt.root.hi[2] : mt.root.lo[2]};
+                for (int k = 0; k < 3; k++) {
+                    const double w = (double)m[k] * v[0] + (double)m[4 + k] * v[1] + (double)m[8 + k] * v[2] + (double)m[12 + k];
+                    wb.lo[k] = std::min(wb.lo[k], (float)w); wb.hi[k] = std::max(wb.hi[k], (float)w);
+                }
+            }
+            for (int k = 0; k < 3; k++) {
+                const float p2 = pad + 1e-6f * std::max(std::fabs(wb.lo[k]), std::fabs(wb.hi[k]));
+                if (!(std::fabs(wb.lo[k]) + p2 < kHugeCoord) || !(std::fabs(wb.hi[k]) + p2 < kHugeCoord)) { wb.lo[k] = -kHugeCoord; wb.hi[k] = kHugeCoord; }
+                else { wb.lo[k] -= p2; wb.hi[k] += p2; }
+            }
+            ref_prim.push_back((uint32_t)(nP + inst_object.size()));
+            boxes.push_back(wb);
+            inst_object.push_back(o);
+        }
+    }
+    const size_t nI = inst_object.size();
+    const size_t nRefs = ref_prim.size();                  // top-level references: nR of primitives, then one per instance
+
     BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct);
     auto t_built = std::chrono::steady_clock::now();
+    if (nI) {
+        // entering an instance costs the exit marker, and a top-level leaf can stack a link per instance record it holds
+        const int need = bvh.stack_need4 + leaf_size + 1 + blas_stack_need;
+        if (need > ctx->stack_limit) { ctx->flatten_once = true; return rebuild_scene(ctx); }
+        bvh.stack_need4 = need;
+    }
 
-    std::vector<float4> recs(nR * 3);
-    std::vector<uint32_t> by_id(nP);
-    for (size_t slot = 0; slot < nR; slot++) {
+    size_t n_recs = nRefs;                                 // records on the device: the top level's, then every mesh tree's
+    for (const MeshTree &mt : mesh_trees) n_recs += mt.recs.size() / 3;
+    if (n_recs >= (1u << 27)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^27 primitive records");
+    std::vector<float4> recs(n_recs * 3);
+    std::vector<uint32_t> by_id(nIds, 0xffffffffu);
+    for (size_t slot = 0; slot < nRefs; slot++) {
         uint32_t prim = ref_prim[bvh.order[slot]];
-        by_id[prim] = (uint32_t)slot;
-        int32_t id = 1 + (int32_t)prim;
+        if (prim >= nP) {                                  // an instance: kind 2, b.x = its index
+            const int32_t ii = (int32_t)(prim - nP), two = 2;
+            float iif, kind; std::memcpy(&iif, &ii, 4); std::memcpy(&kind, &two, 4);
+            recs[slot * 3 + 0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            recs[slot * 3 + 1] = make_float4(iif, 0.0f, 0.0f, kind);
+            recs[slot * 3 + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            continue;
+        }
+        int32_t id = (int)prim < nS ? 1 + (int32_t)prim : 1 + nS + (int32_t)tri_gid[prim - nS];
+        by_id[(size_t)id - 1] = (uint32_t)slot;
         float idf; std::memcpy(&idf, &id, 4);
         if ((int)prim < nS) {
             const PtSphere &s = ctx->spheres[prim];
@@ -386,6 +607,17 @@ int rebuild_scene(pt_context *ctx)
             recs[slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, objf);
         }
     }
+    if (nI) {
+        // a top-level leaf that holds one instance and nothing else: its parent links to the instance itself
+        for (Bvh4Node &nd : bvh.nodes4)
+            for (int k = 0; k < 4; k++) {
+                if (nd.child[k] >= 0) continue;
+                const uint32_t enc = (uint32_t)~nd.child[k];
+                if ((enc & 7u) != 0) continue;
+                const uint32_t prim = ref_prim[bvh.order[enc >> 3]];
+                if (prim >= nP) nd.child[k] = (int32_t)~(kInstanceBit | (uint32_t)(prim - nP));
+            }
+    }
     std::vector<float4> smat((size_t)nS * 4);
     for (int i = 0; i < nS; i++) {
         const PtSphere &s = ctx->spheres[i];
@@ -395,9 +627,55 @@ int rebuild_scene(pt_context *ctx)
         smat[i * 4 + 3] = make_float4(s.emission[0], s.emission[1], s.emission[2], 0.0f);
     }
     int rc;
+    // ---- two-level scenes: the mesh trees follow the top-level tree in the node and record arrays; instance table
+    ctx->n_inst = (int)nI;
+    free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices);
+    if (nI) {
+        std::vector<uint32_t> group_root(groups.size());
+        size_t rec_base = nRefs;
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            MeshTree &mt = mesh_trees[gi];
+            const uint32_t node_base = (uint32_t)bvh.nodes4.size();
+            group_root[gi] = node_base;
+            for (Bvh4Node nd : mt.bvh.nodes4) {
+                for (int k = 0; k < 4; k++) {
+                    if (nd.child[k] >= 0) nd.child[k] += (int32_t)node_base;
+                    else { const uint32_t enc = (uint32_t)~nd.child[k]; nd.child[k] = ~(int32_t)((((enc >> 3) + (uint32_t)rec_base) << 3) | (enc & 7u)); }
+                }
+                bvh.nodes4.push_back(nd);
+            }
+            std::copy(mt.recs.begin(), mt.recs.end(), recs.begin() + rec_base * 3);
+            rec_base += mt.recs.size() / 3;
+            bvh.depth4 = std::max(bvh.depth4, mt.bvh.depth4);
+        }
+        std::vector<float4> inst(nI * 8, make_float4(0, 0, 0, 0));
+        for (size_t ii = 0; ii < nI; ii++) {
+            const int o = inst_object[ii];
+            const float *m = ctx->objects[(size_t)o].local_to_world;
+            double inv[3][4];
+            affine_inverse_rows(m, inv);
+            for (int r = 0; r < 3; r++) {
+                inst[ii * 8 + r] = make_float4(m[r], m[4 + r], m[8 + r], m[12 + r]);
+                inst[ii * 8 + 3 + r] = make_float4((float)inv[r][0], (float)inv[r][1], (float)inv[r][2], (float)inv[r][3]);
+            }
+            const int32_t root = (int32_t)group_root[(size_t)obj_group[(size_t)o]], id0 = 1 + nS + (int32_t)obj_first_tri[(size_t)o], oi = o;
+            float rf, idf, of; std::memcpy(&rf, &root, 4); std::memcpy(&idf, &id0, 4); std::memcpy(&of, &oi, 4);
+            inst[ii * 8 + 6] = make_float4(rf, idf, of, 0.0f);
+        }
+        std::vector<int4> otab(ctx->objects.size() + 1);
+        for (size_t o = 0; o < ctx->objects.size(); o++) otab[o] = make_int4((int)obj_first_tri[o], ctx->objects[o].indices_offset, 0, 0);
+        otab[ctx->objects.size()] = make_int4((int)nt, 0, 0, 0);
+        if ((rc = upload(ctx, ctx->d_inst, inst.data(), inst.size() * sizeof(float4)))) return rc;
+        if ((rc = upload(ctx, ctx->d_objects, otab.data(), otab.size() * sizeof(int4)))) return rc;
+        if ((rc = upload(ctx, ctx->d_indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t)))) return rc;
+        std::vector<float> mats(ctx->objects.size() * 16);
+        for (size_t o = 0; o < ctx->objects.size(); o++) std::memcpy(&mats[o * 16], ctx->objects[o].local_to_world, 64);
+        if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)))) return rc;
+    }
     // ---- what a later refit needs: per slot its source triangle, the object-space vertices, the tree's levels
     ctx->refit_ready = false;
-    if (ctx->refit && !bvh.nodes4.empty()) {
+    if (ctx->refit && !bvh.nodes4.empty() && nI == 0) {
         std::vector<int32_t> tri_obj(tris.size()), tri_i0(tris.size()), tri_i1(tris.size()), tri_i2(tris.size());
         size_t j = 0;
         for (size_t o = 0; o < ctx->objects.size(); o++) {
@@ -464,7 +742,7 @@ int rebuild_scene(pt_context *ctx)
     if ((rc = upload(ctx, ctx->d_by_id, by_id.data(), by_id.size() * sizeof(uint32_t)))) return rc;
     if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
     ctx->n_nodes = (int)bvh.nodes.size();
-    ctx->n_prims = (int)nP;
+    ctx->n_prims = (int)nIds;
     ctx->n_slots = (int)nR;
     ctx->n_spheres = nS;
     ctx->stack_need4 = bvh.stack_need4;
@@ -475,7 +753,7 @@ int rebuild_scene(pt_context *ctx)
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING"))
-        std::fprintf(stderr, "scene build: %zu primitives, %zu references, %zu nodes; prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n", nP, nR, bvh.nodes4.size(),
+        std::fprintf(stderr, "scene build: %zu primitives, %zu references, %zu instances, %zu nodes; prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n", nIds, nR, nI, bvh.nodes4.size(),
                      std::chrono::duration<float, std::milli>(t_prep - t0).count(), std::chrono::duration<float, std::milli>(t_built - t_prep).count(),
                      std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_built).count());
     ctx->scene_dirty = false;
@@ -503,7 +781,7 @@ float reach_needed(const pt_context *ctx, const float *origins, int n, int strid
 int rebuild_scene(pt_context *ctx);
 int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
 {
-    if (tree_width(ctx) == 2 && ctx->bvh2_stale) ctx->scene_dirty = true;
+    if (tree_width(ctx) == 2 && (ctx->bvh2_stale || ctx->n_inst)) ctx->scene_dirty = true;   // the two-child tree is flat and never refitted
     for (int pass = 0; pass < 2; pass++) {
         if (ctx->scene_dirty) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -526,6 +804,8 @@ SceneDev scene_dev(const pt_context *ctx)
     sc.mesh_mat = ctx->d_mesh_mat;
     sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
     sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres; sc.n_nodes4 = ctx->n_nodes4;
+    sc.inst = ctx->d_inst; sc.objects = ctx->d_objects; sc.indices = ctx->d_indices; sc.vertices = ctx->d_vertices; sc.matrices = ctx->d_matrices;
+    sc.n_inst = ctx->n_inst;
     return sc;
 }
 
@@ -627,6 +907,9 @@ int finish_epoch(pt_context *ctx)
         unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int sh = 0; sh < kStatsShards; sh++)
             for (int k = 0; k < 9; k++) ph[k] += part[sh * kStatsStride + 4 + k];
+        unsigned long long life_sum = 0, life_max = 0;
+        for (int sh = 0; sh < kStatsShards; sh++) { life_sum += part[sh * kStatsStride + 13]; life_max = std::max(life_max, part[sh * kStatsStride + 14]); }
+        std::fprintf(stderr, "waves: summed lifetime %.3f ms x waves, longest %.3f ms (100 MHz counter); kernels of the epoch %.3f ms\n", (double)life_sum * 1e-5, (double)life_max * 1e-5, ms);
         const char *names[3] = {"shade", "node", "leaf"};
         for (int k = 0; k < 3; k++)
             std::fprintf(stderr, "phase %-5s rounds %12llu  lanes/round %6.2f  clocks %14llu (%5.1f%%)  clocks/round %8.1f\n", names[k], ph[2 * k],
@@ -688,6 +971,10 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->sched_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_mat_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched_ext_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_inst_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched_inst_blocks_per_cu = std::max(1, bpc);
+    if (std::getenv("PTRACE_BUILD_TIMING"))
+        std::fprintf(stderr, "resident blocks per CU: path_sched_kernel %d, path_sched_mat_kernel %d, path_sched_inst_kernel %d\n", ctx->sched_blocks_per_cu, ctx->sched_ext_blocks_per_cu, ctx->sched_inst_blocks_per_cu);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->pool_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_mat_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
@@ -730,6 +1017,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds); free_dev(ctx->own_display);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices);
+    free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices);
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
     for (int i = 0; i < pt_context::kCamRing; i++) {
@@ -944,7 +1232,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     a.tiles_x = (tw + 7) / 8;
     const int tiles_y = (th + 7) / 8;
     a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
-    const bool extended = ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
+    const bool instanced = ctx->n_inst > 0;        // two-level scene: path_sched_inst_kernel, whatever the backend option says
+    const bool extended = instanced || ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
     // the wavefront stages pack a path's bounce count into 8 bits (pt_wavefront.hpp): longer paths go to the scheduled kernel
     if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary && a.maxb <= 255) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
@@ -994,7 +1283,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
             return PT_OK;
         }
     } after{ctx, a, want_order, key};
-    if (ctx->backend == 2) {
+    if (ctx->backend == 2 && !instanced) {
         // one wave per block, kPoolK * 64 ray slots per wave
         constexpr int P = 64 * kPoolK;
         const int fit = extended ? ctx->pool_ext_blocks_per_cu : ctx->pool_blocks_per_cu;
@@ -1024,13 +1313,15 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         return after.done();
     }
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-    const int fit = extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
+    const int fit = instanced ? ctx->sched_inst_blocks_per_cu : extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
     const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, fit) : fit;
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * per_cu);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
     a.vote_shade = ctx->vote_shade; a.vote_node = ctx->vote_node;
-    if (extended) {
+    if (instanced) {
+        hipLaunchKernelGGL(path_sched_inst_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    } else if (extended) {
         if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_mat_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
@@ -1099,7 +1390,7 @@ static int render_frame(pt_context *ctx, const PtFrameParams *p)
     if (mode != 1 && p->accumulate != PT_ACCUM_NONE)
         return fail(ctx, PT_ERR_INVALID, "pt_render: every renderMode but 1 uses the converged target as its history; accumulate must be PT_ACCUM_NONE");
     if (p->max_bounces < 1 || p->max_bounces > 4095) return fail(ctx, PT_ERR_INVALID, "pt_render: max_bounces must be 1..4095");
-    if (p->samples_per_pixel >= (1 << 20)) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_pixel must be below 2^20 per dispatch");
+    if (p->samples_per_pixel >= (1 << 19)) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_pixel must be below 2^19 per dispatch");
     if (p->accumulate < PT_ACCUM_NONE || p->accumulate > PT_ACCUM_ADDMAT) return fail(ctx, PT_ERR_INVALID, "pt_render: bad accumulate mode");
     int x0 = 0, y0 = 0, tw = ctx->W, th = ctx->H;
     if (p->tile_w > 0 && p->tile_h > 0) { x0 = p->tile_x0; y0 = p->tile_y0; tw = p->tile_w; th = p->tile_h; }
@@ -1293,6 +1584,12 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: refit must be 0 or 1");
         if (value && !ctx->refit) ctx->scene_dirty = true;   // the refit buffers are made by a full build
         ctx->refit = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "instancing") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: instancing must be 0 or 1");
+        if (ctx->instancing != value) ctx->scene_dirty = true;
+        ctx->instancing = value;
         return PT_OK;
     }
     if (std::strcmp(name, "split_percent") == 0) {

@@ -28,5 +28,6 @@ def tracer(request):
     backend, width = request.param.split("-bvh")
     t.set_option("backend", {"sched": 0, "wavefront": 1, "pool": 2}[backend])
     t.set_option("bvh_width", int(width))
+    t.variant = request.param
     yield t
     t.close()

@@ -1187,7 +1187,7 @@ def test_contexts_driven_from_several_threads_at_once(sky_small):
 
 
 def test_many_samples_and_long_paths_in_one_dispatch(tracer, fixture_scene, sky_small):
-    """The lane state packs sample and bounce counters into one word (sample < 2^20, bounce < 4096): 5 000 samples per
+    """The lane state packs sample and bounce counters into one word (sample < 2^19, bounce < 4096): 5 000 samples per
     pixel, and separately 300-segment paths, still match the oracle bit for bit; the limits themselves are rejected."""
     s, orc = fixture_scene
     tracer.load_scene(s, sky_small); tracer.set_mesh_materials(None)      # the shared context may hold another test's scene
@@ -1323,3 +1323,97 @@ def test_large_triangles_are_split_into_references(tracer, sky_small):
         _assert_same_image(tracer.read_result(), g, "full build of the moved scene")
     finally:
         tracer.set_option("refit", 1); tracer.set_option("split_percent", 30)
+
+
+def _trs(angle_deg, t, scale=1.0, axis=1, mirror=False):
+    a = np.radians(angle_deg); c, s = np.cos(a), np.sin(a)
+    r = np.eye(3)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    r[i, i] = c; r[i, j] = -s; r[j, i] = s; r[j, j] = c
+    if mirror:
+        r = r @ np.diag([-1.0, 1.0, 1.0])
+    m = np.eye(4, dtype=np.float32); m[:3, :3] = (r * scale).astype(np.float32); m[:3, 3] = t
+    return m.T.reshape(16).copy()                                    # UnityEngine.Matrix4x4 memory order
+
+
+def test_instances_share_one_tree(tracer, sky_small):
+    """Option "instancing": mesh objects with the same index range, placed by rotation / mirror / uniform scale /
+    translation, keep ONE tree over the mesh's object-space triangles under a top-level tree of instance boxes; a sheared
+    copy and a mesh used once stay flattened.  Image, hit ids and ray count equal the oracle's (which flattens, as the
+    reference's shader does) and the flattened build's bit for bit - with per-object materials too; the tree is a
+    fraction of the size; the exhaustive loop agrees on random rays; after objects move, the next frame still equals
+    the oracle."""
+    f = pa.Scene("fixture")
+    mesh_v = np.array(f.vertices, np.float32).reshape(-1, 3); mesh_i = np.array(f.indices, np.int32)
+    lo, hi = np.float32([-0.7, 0, -0.7]), np.float32([0.7, 1.4, 0.7])
+    box_v = np.array([[(hi if (c >> k) & 1 else lo)[k] for k in range(3)] for c in range(8)], np.float32)
+    box_i = np.array([q for a, b, c, d in [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)] for q in (a, b, c, a, c, d)], np.int32)
+    verts = np.concatenate([mesh_v, box_v]); index = np.concatenate([mesh_i, box_i + len(mesh_v)])
+    n_mesh, n_box = len(mesh_i), len(box_i)
+    shear = _trs(0, (5.0, 1.6, 3.0)).reshape(4, 4).copy(); shear[1, 0] = 0.4           # x picks up y: not a similarity
+    placements = [_trs(0, (-4.0, 1.5, 2.0)), _trs(70, (-1.0, 1.2, 4.0), 0.7), _trs(-130, (2.5, 2.0, 1.0), 1.3, axis=0),
+                  _trs(25, (0.5, 1.4, -2.0), 1.0, axis=2, mirror=True), _trs(200, (4.0, 3.0, 5.0), 2.0), shear.reshape(16)]
+    objs = np.zeros(len(placements) + 2, f.objects.dtype)
+    for k, m in enumerate(placements):
+        objs[k] = (m, 0, n_mesh)
+    objs[-2] = (_trs(15, (-2.5, 0.0, -1.0)), n_mesh, n_box)                              # two small boxes: below the size for instancing
+    objs[-1] = (_trs(-40, (3.0, 0.0, -1.5), 1.5), n_mesh, n_box)
+    W, H = 128, 72
+    cam = dict(eye=(0.5, 5.0, -11.0), target=(0.5, 1.5, 2.0), fov=60)
+    p = pa.make_params(f, W, H, spp=2, max_bounces=5, seed=0.77, **cam)
+    c, cid, cst = po.Oracle(f.spheres, objs, verts, index, sky=sky_small).render(p, W, H, threads=4)
+    tracer.set_spheres(f.spheres); tracer.set_meshes(objs, verts, index); tracer.set_sky(sky_small)
+    tracer.resize(W, H)
+    rng = np.random.default_rng(6)
+    o = rng.uniform(-8, 8, (400, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.3, 8, 400)
+    d = rng.normal(size=(400, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    od = np.concatenate([o, d], 1)
+    try:
+        nodes = {}
+        for inst in (0, 1):
+            tracer.set_option("instancing", inst)
+            tracer.stats()
+            tracer.render(p)
+            g = tracer.read_result(); gid = tracer.read_hit_ids(); st = tracer.stats()
+            assert (gid == cid).all(), inst
+            _assert_same_image(g, c, f"instancing {inst}")
+            assert st["rays"] == cst["rays"] and st["bvh_prims"] == len(f.spheres) + int(objs["count"].sum()) // 3
+            nodes[inst] = st["bvh_nodes"]
+            ib, tb = tracer.trace_rays(od); ie, te = tracer.trace_rays(od, brute_force=True)
+            assert (ib == ie).all() and (_bits(tb) == _bits(te)).all(), inst
+            if inst == 0:
+                ids_flat, t_flat = ib, tb
+            else:
+                assert (ib == ids_flat).all() and (_bits(tb) == _bits(t_flat)).all()
+        assert (cid > len(f.spheres)).mean() > 0.05
+        if tracer.variant.endswith("bvh4"):
+            assert nodes[1] < 0.6 * nodes[0], nodes                  # five of the six copies share one tree
+        else:
+            assert nodes[1] == nodes[0], nodes                       # the two-child tree is always flat
+        # per-object materials reach instanced hits through the object index
+        mats = pa.materials([((0.8, 0.3 + 0.1 * k, 0.2), 0.3 + 0.1 * k, (0.1, 0.2, 0.3), pa.PT_LOBE_GGX if k % 2 else pa.PT_LOBE_PHONG, (0.0, 0.0, 0.5 * (k == 2)))
+                             for k in range(len(objs))])
+        tracer.set_mesh_materials(mats)
+        tracer.render(p)
+        cm, cidm, _ = po.Oracle(f.spheres, objs, verts, index, sky=sky_small, materials=mats).render(p, W, H, threads=4)
+        assert (tracer.read_hit_ids() == cidm).all()
+        _assert_same_image(tracer.read_result(), cm, "instancing with materials")
+        tracer.set_mesh_materials(None)
+        # objects move (one of them into a shear: it leaves the instances)
+        moved = objs.copy()
+        moved["m"][1] = _trs(110, (-1.5, 1.6, 3.0), 0.9)
+        moved["m"][4] = shear.reshape(16) + np.float32(0.0); moved["m"][4][12:15] = (4.0, 3.0, 5.0)
+        moved["m"][0] = _trs(5, (-4.2, 1.5, 2.2))
+        tracer.update_transforms(moved)
+        tracer.render(p)
+        c2, cid2, _ = po.Oracle(f.spheres, moved, verts, index, sky=sky_small).render(p, W, H, threads=4)
+        assert (tracer.read_hit_ids() == cid2).all()
+        _assert_same_image(tracer.read_result(), c2, "instances moved")
+        # _Depth output goes through the same two-level walk
+        pd = pa.make_params(f, W, H, spp=1, max_bounces=1, seed=0.77, depth=1, **cam)
+        tracer.render(pd)
+        cd, cidd, _ = po.Oracle(f.spheres, moved, verts, index, sky=sky_small).render(pd, W, H, threads=4)
+        assert (tracer.read_hit_ids() == cidd).all()
+        _assert_same_image(tracer.read_result(), cd, "instances, _Depth")
+    finally:
+        tracer.set_option("instancing", 0); tracer.set_mesh_materials(None)

@@ -1,6 +1,8 @@
 """Randomised geometry soak (run on the GPU box): small random scenes full of awkward primitives - coincident and
 degenerate triangles, shared vertices, zero / negative / huge radii, NaN and infinite coordinates, empty lists, scaled and
-mirrored object matrices - rendered by libptrace (both tree widths, after a build and after a refit) and by the
+mirrored, turned and sheared object matrices, objects that share a mesh - rendered by libptrace (both tree widths, large
+triangles cut into references or not, shared meshes as instances of one tree or flattened, after a build and after an update
+that moves some of the objects) and by the
 oracle's exhaustive loop; images and hit ids must agree bit for bit.
 usage: python tools/soak_geometry.py [seconds] [seed]"""
 import os
@@ -9,6 +11,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("PTRACE_INSTANCE_MIN_TRIS", "1")      # the soak's meshes are tiny: let them be instances all the same
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pathtracing_amd as pa  # noqa: E402
@@ -49,9 +52,20 @@ def run(budget=60.0, seed=1):
         bounds = [0] + list(cuts) + [nt]
         for o in range(n_obj):
             m = np.eye(4, dtype=np.float32)
+            if rng.random() < 0.5:                                           # turned about a random axis
+                ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 2 * np.pi)
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                m[:3, :3] = (np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K).astype(np.float32)
             m[:3, :3] *= rng.choice([1.0, 1.0, 0.5, 2.0, -1.0])
+            if rng.random() < 0.15:
+                m[int(rng.integers(0, 3)), int(rng.integers(0, 3))] += rng.choice([0.3, -0.7])      # a shear: never an instance
             m[:3, 3] = rng.uniform(-1, 1, 3)
             objs[o] = (m.T.reshape(16), 3 * bounds[o], 3 * (bounds[o + 1] - bounds[o]))
+        if n_obj >= 2 and rng.random() < 0.6:                                # objects that share a mesh: instances when the option is on
+            src = int(rng.integers(0, n_obj))
+            for o in range(n_obj):
+                if o != src and rng.random() < 0.7:
+                    objs[o]["offset"] = objs[src]["offset"]; objs[o]["count"] = objs[src]["count"]
         return sph, objs, v, idx.reshape(-1)
 
 
@@ -81,6 +95,8 @@ def run(budget=60.0, seed=1):
             mats = pa.materials(ent)
         width = int(rng.choice([2, 4]))
         t.set_option("bvh_width", width)
+        t.set_option("split_percent", int(rng.choice([0, 30, 30, 400])))
+        t.set_option("instancing", int(rng.random() < 0.6))
         t.set_spheres(sph); t.set_meshes(objs, v, idx); t.set_sky(sky); t.resize(W, H)
         t.set_mesh_materials(mats)
         orc = po.Oracle(sph, objs, v, idx, sky=sky, accel=False, materials=mats)
@@ -92,7 +108,8 @@ def run(budget=60.0, seed=1):
         if ok and len(objs):
             stage = "refit"
             objs2 = objs.copy()
-            objs2["m"][:, 12:15] += rng.uniform(-0.5, 0.5, (len(objs), 3)).astype(np.float32)
+            still = rng.random(len(objs)) < 0.4                             # some objects stay: their split triangles keep their cut boxes
+            objs2["m"][:, 12:15] += np.where(still[:, None], 0.0, rng.uniform(-0.5, 0.5, (len(objs), 3))).astype(np.float32)
             t.update_transforms(objs2)
             t.render(p)
             c2, cid2, _ = po.Oracle(sph, objs2, v, idx, sky=sky, accel=False, materials=mats).render(p, W, H, threads=4)
