@@ -1032,8 +1032,14 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
         const bool waiting = node == kDoneNode || node == kIdleNode;
         const int n_inner = __popcll(__ballot(inner)), n_leaf = __popcll(__ballot(leaf)), n_wait = __popcll(__ballot(waiting));
         if (n_inner + n_leaf + n_wait == 0) break;
+        // The votes are fractions of the lanes that still have work: once the frame is drained and lanes retire, a wave of ten
+        // live lanes must not wait for 44 of them to finish a ray - it would only shade when all ten have, and every bounce
+        // would take as long as the slowest of ten rays.
+        const int n_live = n_inner + n_leaf + n_wait;
+        const int vote_shade = n_live == 64 ? a.vote_shade : max(1, (a.vote_shade * n_live) >> 6);
+        const int vote_node = n_live == 64 ? a.vote_node : max(1, (a.vote_node * n_live) >> 6);
 
-        if (n_wait >= a.vote_shade || n_inner + n_leaf == 0) {
+        if (n_wait >= vote_shade || n_inner + n_leaf == 0) {
             // ================= shade phase =================
 #ifdef PT_PROFILE_PHASES
             ph_rounds[0]++; ph_lanes[0] += n_wait; PH_SWITCH(0)
@@ -1221,7 +1227,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             continue;
         }
 
-        if (n_inner >= a.vote_node || n_leaf == 0) {
+        if (n_inner >= vote_node || n_leaf == 0) {
             // ================= node phase =================
 #ifdef PT_PROFILE_PHASES
             ph_rounds[1]++; ph_lanes[1] += n_inner; PH_SWITCH(1)
@@ -1235,9 +1241,9 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                 }
                 const int still = __popcll(__ballot(node >= 0));
 #ifdef PT_PROFILE_PHASES
-                if (still >= a.vote_node) { ph_rounds[1]++; ph_lanes[1] += still; }
+                if (still >= vote_node) { ph_rounds[1]++; ph_lanes[1] += still; }
 #endif
-                if (still < a.vote_node) break;
+                if (still < vote_node) break;
             }
             continue;
         }
