@@ -23,6 +23,17 @@
 
 using namespace ptrace;
 
+// The tree over one shared mesh's object-space triangles (two-level scenes), kept between builds: moving instances
+// then costs the top-level tree only.  Valid while the geometry is the one of the last pt_set_meshes and the padding it was
+// built with still covers what a build asks for.
+struct CachedMesh {
+    int32_t indices_offset = 0, indices_count = 0, leaf_size = 0;
+    float pad = 0.0f, reach = 0.0f;       // object-space box padding and intersection reach the boxes were made for
+    BvhResult bvh;
+    std::vector<float4> recs;             // (v0, triangle index within the mesh) (v1, 0) (v2, 0) in tree order
+    Aabb root;                            // union of the padded boxes
+};
+
 struct pt_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -83,6 +94,7 @@ struct pt_context {
     int n_inst = 0;                   // instances in the current build (0: everything flattened)
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
     float4 *d_inst = nullptr;         // SceneDev::inst
+    std::vector<CachedMesh> mesh_cache;
     int4 *d_objects = nullptr;        // SceneDev::objects
     int32_t *d_indices = nullptr;     // SceneDev::indices
 
@@ -363,22 +375,35 @@ int rebuild_scene(pt_context *ctx)
     if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, obj_group);
 #endif
     ctx->flatten_once = false;
-    tris.reserve(nt); tri_object.reserve(nt); tri_gid.reserve(nt);
+    std::vector<Aabb> group_bounds(groups.size()); std::vector<char> group_bounds_done(groups.size(), 0);
+    {
+        size_t n_flat = 0;
+        for (size_t oi = 0; oi < ctx->objects.size(); oi++)
+            if (obj_group[oi] < 0) n_flat += obj_first_tri[oi + 1] - obj_first_tri[oi];
+        tris.reserve(n_flat); tri_object.reserve(n_flat); tri_gid.reserve(n_flat);
+    }
     ctx->object_box.assign(ctx->objects.size(), Aabb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}});
     for (size_t oi = 0; oi < ctx->objects.size(); oi++) {
         const PtMeshObject &mo = ctx->objects[oi];
         const int32_t end = mo.indices_offset + mo.indices_count;
         Aabb &ob = ctx->object_box[oi];
         uint32_t gid = obj_first_tri[oi];
-        for (int32_t i = mo.indices_offset; i + 2 < end; i += 3, gid++) {
-            if (obj_group[oi] >= 0) {      // instanced: only the object-space bounds are needed here
-                for (int c = 0; c < 3; c++) {
-                    const float *v = &ctx->vertices[3 * (size_t)ctx->indices[i + c]];
-                    for (int k = 0; k < 3; k++)
-                        if (std::fabs(v[k]) < kHugeCoord) { ob.lo[k] = std::min(ob.lo[k], v[k]); ob.hi[k] = std::max(ob.hi[k], v[k]); }
-                }
-                continue;
+        if (obj_group[oi] >= 0) {          // instanced: only the object-space bounds are needed here, once per shared mesh
+            const size_t gi = (size_t)obj_group[oi];
+            if (!group_bounds_done[gi]) {
+                Aabb gb; box_reset_inf(gb);
+                for (int32_t i = mo.indices_offset; i + 2 < end; i += 3)
+                    for (int c = 0; c < 3; c++) {
+                        const float *v = &ctx->vertices[3 * (size_t)ctx->indices[i + c]];
+                        for (int k = 0; k < 3; k++)
+                            if (std::fabs(v[k]) < kHugeCoord) { gb.lo[k] = std::min(gb.lo[k], v[k]); gb.hi[k] = std::max(gb.hi[k], v[k]); }
+                    }
+                group_bounds[gi] = gb; group_bounds_done[gi] = true;
             }
+            ob = group_bounds[gi];
+            continue;
+        }
+        for (int32_t i = mo.indices_offset; i + 2 < end; i += 3, gid++) {
             tri_object.push_back((int32_t)oi);
             tri_gid.push_back(gid);
             const float *a = &ctx->vertices[3 * (size_t)ctx->indices[i]];
@@ -498,21 +523,35 @@ int rebuild_scene(pt_context *ctx)
     auto t_prep = std::chrono::steady_clock::now();
 
     // ---- two-level scenes: one tree per shared mesh over its object-space triangles, one top-level reference per instance
-    struct MeshTree { BvhResult bvh; std::vector<float4> recs; Aabb root; };
-    std::vector<MeshTree> mesh_trees(groups.size());
+    typedef CachedMesh MeshTree;
+    std::vector<const MeshTree *> mesh_trees(groups.size(), nullptr);
     std::vector<int> inst_object;          // instance -> mesh object
     int blas_stack_need = 0;
+    if (groups.empty()) ctx->mesh_cache.clear();
+    ctx->mesh_cache.reserve(ctx->mesh_cache.size() + groups.size());      // pointers into it stay valid through the loop
     for (size_t gi = 0; gi < groups.size(); gi++) {
         const MeshGroup &g = groups[gi];
-        MeshTree &mt = mesh_trees[gi];
         const size_t n = (size_t)g.indices_count / 3;
         // How far, in object space, the ray's point at the hit's parameter can lie from the object-space triangle when the
         // world-space test accepts the hit: the world padding of the flattened tree, the rounding of the world vertices and
         // of the ray's transform (coordinates up to `coord`, a few ulps each), all taken through the inverse map.
         float coord = reach;
         for (int k = 0; k < 3; k++) coord = std::max(coord, std::max(std::fabs(ctx->scene_lo[k]), std::fabs(ctx->scene_hi[k])) + reach);
-        const float pad_o = (float)(g.inv_norm * 1.25 * ((double)pad + 4.8e-7 * (3.0 * coord + reach)));
-        const float reach_o = (float)(reach / g.scale_min);
+        const float pad_need = (float)(g.inv_norm * 1.25 * ((double)pad + 4.8e-7 * (3.0 * coord + reach)));
+        const float reach_need = (float)(reach / g.scale_min);
+        // a kept tree serves if it was padded for at least this much and not for absurdly more; a new one gets some room, so
+        // that instances can move and the scene can grow a little before the mesh has to be built again
+        CachedMesh *hit = nullptr;
+        for (CachedMesh &cm : ctx->mesh_cache)
+            if (cm.indices_offset == g.indices_offset && cm.indices_count == g.indices_count) hit = &cm;
+        if (hit && hit->leaf_size == leaf_size && hit->pad >= pad_need && hit->pad <= 1.3f * pad_need && hit->reach >= reach_need && hit->reach <= 2.0f * reach_need) {
+            mesh_trees[gi] = hit;
+        } else {
+        if (!hit) { ctx->mesh_cache.emplace_back(); hit = &ctx->mesh_cache.back(); }
+        CachedMesh &mt = *hit;
+        mt.indices_offset = g.indices_offset; mt.indices_count = g.indices_count; mt.leaf_size = leaf_size;
+        const float pad_o = 1.1f * pad_need, reach_o = 1.25f * reach_need;      // wider boxes cost rays: 1.5 x the padding is 20 % fewer rays per second
+        mt.pad = pad_o; mt.reach = reach_o;
         std::vector<Aabb> ob(n);
         box_reset_inf(mt.root);
         for (size_t t = 0; t < n; t++) {
@@ -530,7 +569,7 @@ int rebuild_scene(pt_context *ctx)
             }
         }
         mt.bvh = build_bvh(ob, leaf_size, 0, ct);
-        blas_stack_need = std::max(blas_stack_need, mt.bvh.stack_need4);
+        mt.bvh.nodes.clear(); mt.bvh.nodes.shrink_to_fit();      // the two-child tree is not used for instances
         mt.recs.resize(n * 3);
         for (size_t slot = 0; slot < n; slot++) {
             const uint32_t t = mt.bvh.order[slot];
@@ -541,6 +580,10 @@ int rebuild_scene(pt_context *ctx)
             mt.recs[slot * 3 + 1] = make_float4(b[0], b[1], b[2], 0.0f);
             mt.recs[slot * 3 + 2] = make_float4(c[0], c[1], c[2], 0.0f);
         }
+        mesh_trees[gi] = &mt;
+        }
+        const MeshTree &mt = *mesh_trees[gi];
+        blas_stack_need = std::max(blas_stack_need, mt.bvh.stack_need4);
         // a top-level reference per member: the world box of the mesh's root box under the member's matrix
         for (int o : g.objects) {
             const float *m = ctx->objects[(size_t)o].local_to_world;
@@ -575,7 +618,7 @@ int rebuild_scene(pt_context *ctx)
     }
 
     size_t n_recs = nRefs;                                 // records on the device: the top level's, then every mesh tree's
-    for (const MeshTree &mt : mesh_trees) n_recs += mt.recs.size() / 3;
+    for (const MeshTree *mt : mesh_trees) n_recs += mt->recs.size() / 3;
     if (n_recs >= (1u << 27)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^27 primitive records");
     std::vector<float4> recs(n_recs * 3);
     std::vector<uint32_t> by_id(nIds, 0xffffffffu);
@@ -634,7 +677,7 @@ int rebuild_scene(pt_context *ctx)
         std::vector<uint32_t> group_root(groups.size());
         size_t rec_base = nRefs;
         for (size_t gi = 0; gi < groups.size(); gi++) {
-            MeshTree &mt = mesh_trees[gi];
+            const MeshTree &mt = *mesh_trees[gi];
             const uint32_t node_base = (uint32_t)bvh.nodes4.size();
             group_root[gi] = node_base;
             for (Bvh4Node nd : mt.bvh.nodes4) {
@@ -1064,6 +1107,7 @@ int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, c
     ctx->objects.assign(objects, objects + n_objects);
     ctx->vertices.assign(vertices, vertices + (size_t)n_vertices * 3);
     ctx->indices.assign(indices, indices + n_indices);
+    ctx->mesh_cache.clear();
     ctx->scene_dirty = true;
     if (!ctx->materials.empty()) {            // materials belong to the object list they were given for
         DeviceGuard g(ctx->device);

@@ -33,9 +33,17 @@ def main():
                 if best is None or st["kernel_ms"] < best["kernel_ms"]:
                     best = st
             img = tr.read_result()
+            # one object moves: what the next frame costs on the host side (refit of the flat tree / new top-level tree)
+            objs = scene.objects.copy()
+            upd = []
+            for step in range(3):
+                objs["m"][3][12] += 0.25
+                tr.sync(); t1 = time.time()
+                tr.update_transforms(objs); tr.render(p); tr.sync()
+                upd.append((time.time() - t1) * 1e3 - tr.stats()["kernel_ms"])
             print(f"instancing {inst}: build {st0['bvh_build_ms']:8.1f} ms (first frame {first:5.2f} s)  nodes {best['bvh_nodes']:8d}  "
                   f"{best['rays'] / best['kernel_ms'] / 1e3:8.1f} Mrays/s  kernel {best['kernel_ms']:7.2f} ms  nodes/ray {best['nodes_visited'] / best['rays']:6.2f}  "
-                  f"prims/ray {best['prims_tested'] / best['rays']:5.2f}  crc {zlib.crc32(img.tobytes())}", flush=True)
+                  f"prims/ray {best['prims_tested'] / best['rays']:5.2f}  crc {zlib.crc32(img.tobytes())}  a moved object costs {min(upd):6.1f} ms before the frame", flush=True)
 
 
 if __name__ == "__main__":
