@@ -99,12 +99,12 @@ def gpu_stripe_sequence(tracer, scene, W, H, n_frames, divisions, mode, **kw):
 # ---- renderMode 11 / 12: the frame and camera of the moment the host switched to the pause mode stay in Result1 and in
 # the history arrays (RayTracingMaster.cs:513-526 uploads an empty list from then on) while the camera moves on
 
-def pause_frames(scene, W, H, n_warm, n_paused, mode, spp=1, max_bounces=4, step=(0.12, 0.05, 0.2), depth=0):
-    """Per frame: (PtFrameParams, history list uploaded before the dispatch); n_warm frames of renderMode 2 first."""
+def pause_frames(scene, W, H, n_warm, n_paused, mode, spp=1, max_bounces=4, step=(0.12, 0.05, 0.2), depth=0, warm_mode=2):
+    """Per frame: (PtFrameParams, history list uploaded before the dispatch); n_warm frames of renderMode `warm_mode` first."""
     out = []
     hist = []
     for k in range(n_warm + n_paused):
-        m = 2 if k < n_warm else mode
+        m = warm_mode if k < n_warm else mode
         p, h = frame_params(scene, W, H, k, 1 if m >= 10 else spp, max_bounces, 5, step=step, mode=m, depth=depth if m >= 10 else 0)
         out.append((p, list(hist)))
         hist = [h] if m < 11 else []                            # :513-526: cleared every frame, refilled only below mode 11

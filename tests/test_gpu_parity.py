@@ -695,6 +695,29 @@ def test_pause_modes_match_oracle_bit_exact(tracer, mode):
     assert got[3][3]["rays"] == (0 if mode == 11 else W * H)
 
 
+@pytest.mark.parametrize("mode", [11, 12])
+def test_plain_mode_keeps_the_previous_frame_for_the_pause_modes(tracer, mode):
+    """RayTracingShader.compute:728-731 copies Result to Result1 at the start of a renderMode 1 dispatch too (the
+    condition covers modes 1, 2, 3, 4 and 10), so a switch from the plain mode to PlanerPause / DepthPause re-projects
+    the second-last plain frame.  Two plain frames, then three paused ones: after the second plain frame Result1 IS
+    the first plain frame - a fact about the reference, not a choice shared with the oracle - and every frame of the
+    sequence equals the oracle's in both targets."""
+    from reproj_util import gpu_pause_sequence, oracle_pause_sequence
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(128, 64)
+    W, H = 64, 36
+    o = po.Oracle.from_scene(s, sky)
+    tracer.load_scene(s, sky); tracer.resize(W, H)
+    want = oracle_pause_sequence(o, s, W, H, 2, 3, mode, warm_mode=1)
+    got = gpu_pause_sequence(tracer, s, W, H, 2, 3, mode, warm_mode=1)
+    assert (got[1][1].view(np.uint32) == got[0][0].view(np.uint32)).all() and (got[0][0][..., :3] > 0).mean() > 0.4
+    assert not (got[1][0] == got[0][0]).all()
+    for k in range(5):
+        assert (got[k][0].view(np.uint32) == want[k][0].view(np.uint32)).all(), f"Result, frame {k}"
+        assert (got[k][1].view(np.uint32) == want[k][1].view(np.uint32)).all(), f"Result1, frame {k}"
+    assert (got[4][1] == got[1][1]).all()                                   # untouched while paused
+    assert (got[4][0][..., :3] > 0).mean() > 0.3
+
+
 def test_pause_mode_depth_and_errors(tracer):
     s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
     W, H = 40, 24
