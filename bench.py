@@ -176,7 +176,8 @@ def setup_dist(args):
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PTRACE_BENCH_FORCE_DIST=1: a process group of one rank too, so that a single GPU can rehearse the RCCL calls themselves
+    if world > 1 or (os.environ.get("PTRACE_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
         # "nccl" is RCCL.  PTRACE_BENCH_BACKEND=gloo (with PTRACE_BENCH_DEVICE) rehearses the N > 1 code on a box with one GPU,
         # where RCCL refuses two ranks on one device; the collectives then go through host memory.
@@ -287,6 +288,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A context hands out pixel blocks by what they cost in its previous dispatch over the same rectangle; with fewer warm-up
+    # steps than contexts some context would meet the timed region without that, so those render one untimed frame first.
+    for i in range(min(args.warmup, n_ctx), n_ctx):
+        trs[i].render(pa.make_params(scene, W, H, seed=0.123, spp=args.spp, max_bounces=args.bounces))
     warm = 0 if strong else args.warmup
     if strong:
         # warm-up frames are extra frames that are not part of the image
