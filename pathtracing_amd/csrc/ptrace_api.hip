@@ -250,14 +250,23 @@ void free_dev(T *&p)
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+// Host to device on the context's stream, complete on return.  (hipMemcpy and hipMemset work on the null stream, which the
+// context's non-blocking stream does not wait for, and may return before a small transfer or a fill has reached the device:
+// a kernel launched right after could still see the old contents.)
+int h2d(pt_context *ctx, void *dst, const void *src, size_t bytes)
+{
+    PT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 template <class T>
 int upload(pt_context *ctx, T *&dst, const void *src, size_t bytes)
 {
     free_dev(dst);
     if (bytes == 0) return PT_OK;
     PT_HIP(ctx, hipMalloc((void **)&dst, bytes));
-    PT_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
-    return PT_OK;
+    return h2d(ctx, dst, src, bytes);
 }
 
 static inline void box_reset_inf(Aabb &b)
@@ -1161,7 +1170,7 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     if (ctx->refit_in_flight) { PT_HIP(ctx, hipEventSynchronize(ctx->ev_refit)); ctx->refit_in_flight = false; }   // d_matrices is free again
     std::vector<float> mats((size_t)n_objects * 16);
     for (int o = 0; o < n_objects; o++) std::memcpy(&mats[(size_t)o * 16], objects[o].local_to_world, 64);
-    PT_HIP(ctx, hipMemcpy(ctx->d_matrices, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
+    { const int rc = h2d(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)); if (rc) return rc; }
     RefitArgs ra;
     ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
     ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
@@ -1235,13 +1244,17 @@ int pt_resize(pt_context *ctx, int width, int height)
     ctx->screen_pixels = 0;
     size_t n = (size_t)width * height;
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_result2, n * sizeof(float4)));
-    PT_HIP(ctx, hipMemset(ctx->own_result2, 0, n * sizeof(float4)));
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_result, n * sizeof(float4)));
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_conv, n * sizeof(float4)));
     PT_HIP(ctx, hipMalloc((void **)&ctx->own_ids, n * sizeof(int32_t)));
-    PT_HIP(ctx, hipMemset(ctx->own_result, 0, n * sizeof(float4)));
-    PT_HIP(ctx, hipMemset(ctx->own_conv, 0, n * sizeof(float4)));
-    PT_HIP(ctx, hipMemset(ctx->own_ids, 0xff, n * sizeof(int32_t)));
+    // Cleared on the context's stream and waited for: hipMemset returns before a device fill has run and fills on the null
+    // stream, which a non-blocking stream does not wait for - the next frame's kernels could read the new targets (recycled
+    // memory) before the zeros arrived.
+    PT_HIP(ctx, hipMemsetAsync(ctx->own_result2, 0, n * sizeof(float4), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->own_result, 0, n * sizeof(float4), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->own_conv, 0, n * sizeof(float4), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->own_ids, 0xff, n * sizeof(int32_t), ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->W = width; ctx->H = height;
     if (rebind_r || !ctx->result) ctx->result = ctx->own_result;
     if (rebind_c || !ctx->conv) ctx->conv = ctx->own_conv;
@@ -1705,8 +1718,7 @@ int pt_write_converged(pt_context *ctx, const float *in)
     if (!in || ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_write_converged: bad arguments");
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemcpy(ctx->conv, in, (size_t)ctx->W * ctx->H * 16, hipMemcpyHostToDevice));
-    return PT_OK;
+    return h2d(ctx, ctx->conv, in, (size_t)ctx->W * ctx->H * 16);
 }
 
 static float4 *target_of(pt_context *ctx, int which)
@@ -1733,8 +1745,7 @@ int pt_write_target(pt_context *ctx, int which, const float *in)
     if (!in || ctx->W == 0 || !dst) return fail(ctx, PT_ERR_INVALID, "pt_write_target: bad arguments");
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemcpy(dst, in, (size_t)ctx->W * ctx->H * 16, hipMemcpyHostToDevice));
-    return PT_OK;
+    return h2d(ctx, dst, in, (size_t)ctx->W * ctx->H * 16);
 }
 
 int pt_get_stats(pt_context *ctx, PtStats *out)
@@ -1764,7 +1775,7 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     if ((e = hipMalloc((void **)&d_od, (size_t)n_rays * 24)) != hipSuccess ||
         (e = hipMalloc((void **)&d_t, (size_t)n_rays * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&d_id, (size_t)n_rays * 4)) != hipSuccess ||
-        (e = hipMemcpy(d_od, origins_dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpyAsync(d_od, origins_dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) {
         cleanup();
         return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
     }

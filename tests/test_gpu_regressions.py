@@ -280,3 +280,31 @@ def test_master_mirror_skybox_from_a_radiance_picture(tmp_path):
         assert b"cannot open" in lib.ptm_master_error(h)
     finally:
         lib.ptm_master_destroy(h)
+
+
+def test_new_targets_are_zero_before_the_next_frame_reads_them():
+    """tools/soak_master.py 150 4242, frame 5162: the first PlanerPause frame after a change of size showed colours of
+    frames long gone.  pt_resize cleared its new targets with hipMemset - a fill on the null stream that returns before
+    it has run - and the context's stream is non-blocking, so the next frame's kernels could read the recycled memory
+    between two of the fills.  Here, a few thousand times: targets full of sevens, a change of size (a handful of small
+    sizes in turn, so that the allocator hands the old blocks out again), at once a renderMode 2 frame, whose prologue
+    copies Result to Result1 (RayTracingShader.compute:728-731) - Result1 must then be zero everywhere, and the frame,
+    which blends in what the history shows, must not contain a seven."""
+    from reproj_util import frame_params
+    s = pa.Scene("fixture"); sky = pa.procedural_sky(64, 32)
+    sizes = [(57, 40), (47, 15), (64, 36), (35, 39), (40, 24)]
+    with pa.PathTracer(0) as t:
+        t.load_scene(s, sky)
+        for it in range(3000):
+            W, H = sizes[it % len(sizes)]
+            t.resize(W, H)
+            p, h = frame_params(s, W, H, it % 7, 1, 2, 5, mode=2)
+            t.set_camera_history([h])
+            t.render(p)
+            conv = t.read_converged()
+            assert not conv.any(), f"iteration {it}: Result1 holds {int((conv != 0).any(-1).sum())} pixels of recycled memory"
+            res = t.read_result()
+            assert np.isfinite(res).all() and not (res == 7.0).any(), f"iteration {it}: the frame shows recycled memory"
+            sevens = np.full((H, W, 4), 7.0, np.float32)
+            for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED, pa.PT_TARGET_DENOISED):
+                t.write_target(which, sevens)
