@@ -63,6 +63,7 @@ struct pt_context {
     bool refit_ready = false;                      // the buffers below describe the current tree
     int4 *d_slot_src = nullptr;
     float *d_vertices = nullptr, *d_matrices = nullptr, *d_prim_box = nullptr, *d_node_box = nullptr;
+    float *h_matrices = nullptr; size_t h_matrices_objects = 0;   // pinned staging for pt_update_transforms (free again once ev_refit has passed)
     int32_t *d_level_nodes = nullptr;
     std::vector<int> level_first;                  // level_first[l] .. level_first[l+1]: nodes of level l, deepest level first
     float box_pad = 0.0f, sphere_slack2 = 0.0f;    // what the last full build padded boxes with
@@ -1070,6 +1071,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices);
     free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices);
+    if (ctx->h_matrices) { (void)hipHostFree(ctx->h_matrices); ctx->h_matrices = nullptr; }
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
     for (int i = 0; i < pt_context::kCamRing; i++) {
@@ -1168,9 +1170,14 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     DeviceGuard g(ctx->device);
     auto t0 = std::chrono::steady_clock::now();
     if (ctx->refit_in_flight) { PT_HIP(ctx, hipEventSynchronize(ctx->ev_refit)); ctx->refit_in_flight = false; }   // d_matrices is free again
-    std::vector<float> mats((size_t)n_objects * 16);
-    for (int o = 0; o < n_objects; o++) std::memcpy(&mats[(size_t)o * 16], objects[o].local_to_world, 64);
-    { const int rc = h2d(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)); if (rc) return rc; }
+    // the matrices go through a pinned buffer of the context's, on its stream: nothing waits here for the frame in flight
+    if (ctx->h_matrices_objects < (size_t)n_objects) {
+        if (ctx->h_matrices) { (void)hipHostFree(ctx->h_matrices); ctx->h_matrices = nullptr; ctx->h_matrices_objects = 0; }
+        PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_matrices, (size_t)n_objects * 64, hipHostMallocDefault));
+        ctx->h_matrices_objects = (size_t)n_objects;
+    }
+    for (int o = 0; o < n_objects; o++) std::memcpy(ctx->h_matrices + (size_t)o * 16, objects[o].local_to_world, 64);
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_matrices, ctx->h_matrices, (size_t)n_objects * 64, hipMemcpyHostToDevice, ctx->stream));
     RefitArgs ra;
     ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
     ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
