@@ -841,7 +841,7 @@ int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
             int rc = rebuild_scene(ctx);
             if (rc) return rc;
         }
-        if (ctx->spheres.empty()) break;
+        if (ctx->spheres.empty() && ctx->n_inst == 0) break;      // only sphere boxes and instanced meshes' boxes are padded by the reach
         const float need = reach_needed(ctx, origins, n, stride);
         if (!(need > ctx->sphere_reach)) break;
         ctx->sphere_reach_request = 2.0f * need;
@@ -1814,9 +1814,9 @@ int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: at most " + std::to_string(kStaticMaxRays) + " rays per call (PT_TRACE_RAYS_STATIC_MAX)");
     if (n_rays == 0) return PT_OK;
     // Building or re-inflating the scene allocates; this call does not, so the scene must be ready.
-    if (ctx->scene_dirty || (tree_width(ctx) == 2 && ctx->bvh2_stale))
+    if (ctx->scene_dirty || (tree_width(ctx) == 2 && (ctx->bvh2_stale || ctx->n_inst)))
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: the scene has changed since it was last built; call pt_render or pt_trace_rays once first");
-    if (!ctx->spheres.empty() && reach_needed(ctx, origins_dirs, n_rays, 6) > ctx->sphere_reach)
+    if ((!ctx->spheres.empty() || ctx->n_inst) && reach_needed(ctx, origins_dirs, n_rays, 6) > ctx->sphere_reach)
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: a ray starts farther from the scene than its tree was built for; call pt_trace_rays once with such rays first");
     unsigned char *base = scratch_of(ctx->device);
     if (!base) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_trace_rays_static: no scratch array on this device (ordinal beyond " + std::to_string(kMaxScratchDevices - 1) + ")");

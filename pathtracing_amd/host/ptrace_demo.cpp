@@ -3,7 +3,10 @@
 // device-counted rays, the time and a checksum of the image; optionally writes the image as a binary PPM.
 //
 //   ptrace_demo [--scene hall260k] [--size 1920x1080] [--spp 16] [--bounces 8] [--frames 5] [--mode 1]
-//               [--accumulate 0|1|2|3] [--device 0] [--ppm out.ppm]
+//               [--accumulate 0|1|2|3] [--device 0] [--ppm out.ppm] [--sky picture.hdr] [--option name=value ...]
+//
+// --sky: a Radiance .hdr picture as SkyboxTexture instead of the procedural sky; --option: pt_set_option before the first
+// frame (e.g. --option instancing=1 for a scene of many copies of one mesh, --option backend=2).
 //
 // The checksum is the XOR of the image's 32-bit words: equal to what bench.py and the tests compute from the same frames.
 #include <chrono>
@@ -13,6 +16,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ray_tracing_master.hpp"
@@ -25,7 +29,8 @@ static int fail(const char *what, const std::string &why)
 
 int main(int argc, char **argv)
 {
-    std::string scene_name = "hall260k", ppm;
+    std::string scene_name = "hall260k", ppm, sky;
+    std::vector<std::pair<std::string, int>> options;
     int W = 1920, H = 1080, spp = 16, bounces = 8, frames = 5, mode = 1, device = 0, accumulate = PT_ACCUM_NONE;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -39,6 +44,13 @@ int main(int argc, char **argv)
         else if (a == "--accumulate") accumulate = std::atoi(next());
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--ppm") ppm = next();
+        else if (a == "--sky") sky = next();
+        else if (a == "--option") {
+            const std::string o = next();
+            const size_t eq = o.find('=');
+            if (eq == std::string::npos) return fail("--option", "expected name=value");
+            options.push_back({o.substr(0, eq), std::atoi(o.c_str() + eq + 1)});
+        }
         else return fail("unknown argument", a);
     }
     std::unique_ptr<ptm::Scene> scene(ptm::Scene::create(scene_name));
@@ -53,6 +65,9 @@ int main(int argc, char **argv)
     std::memcpy(master.target, scene->target, sizeof master.target);
     master.fieldOfView = scene->fov;
     if (master.OnEnable(*scene, 2048, 1024)) return fail("OnEnable", master.error());
+    if (!sky.empty() && master.SetSkyboxTexture(sky.c_str())) return fail("--sky", master.error());
+    for (const auto &o : options)
+        if (pt_set_option(master.context(), o.first.c_str(), o.second)) return fail("--option", pt_last_error(master.context()));
 
     if (master.Render()) return fail("Render", master.error());      // first frame: builds the acceleration structure
     PtStats st;

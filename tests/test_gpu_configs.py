@@ -102,6 +102,18 @@ def test_ten_million_triangles_4k_stereo_with_depth_for_reprojection():
             assert _same(f1[ys, xs], res[ys, xs])
             blended = ~_bitsame(f1[ys, xs], _plain_tile(orc, s, W, H, tile, eye1, target))
             assert blended.mean() > 0.3                                     # the history was actually used
+            if e == 0:
+                # the same eye through the two-level tree (38 placements of one mesh keep one tree): the whole 4K frame, its
+                # hit ids and the _Depth frame are the flattened tree's, bit for bit; the tree is a fraction of the size
+                nodes_flat = t.stats()["bvh_nodes"]
+                t.set_option("instancing", 1)
+                t.stats(); t.render(p0)
+                g0 = t.read_result(); gids = t.read_hit_ids(); st1 = t.stats()
+                assert (gids == ids).all() and _same(g0, f0) and st1["rays"] == st["rays"]
+                assert st1["bvh_nodes"] < nodes_flat // 20 and st1["bvh_prims"] == st["bvh_prims"]
+                t.render(pa.make_params(s, W, H, depth=1, eye=eye, target=target))
+                assert _same(t.read_result(), dep)
+                t.set_option("instancing", 0)
 
 
 def _bitsame(a, b):

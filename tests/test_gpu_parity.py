@@ -1094,6 +1094,14 @@ def test_compiled_host_renders_what_the_ctypes_harness_renders():
     assert np.allclose(img[..., :3].reshape(-1, 3).mean(0), rep["image_mean_rgb"], rtol=1e-4)
     bad = subprocess.run([exe, "--scene", "nowhere"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "unknown scene" in bad.stderr
+    # options before the first frame: another kernel, the same frames
+    for opt in ("backend=2", "split_percent=0", "instancing=1"):
+        alt = subprocess.run([exe, "--scene", "fixture", "--size", f"{W}x{H}", "--spp", "2", "--bounces", "4", "--frames", str(frames), "--option", opt],
+                             capture_output=True, text=True, timeout=120)
+        assert alt.returncode == 0, alt.stderr
+        assert json.loads(alt.stdout.strip().splitlines()[-1])["image_crc"] == rep["image_crc"], opt
+    bad = subprocess.run([exe, "--scene", "fixture", "--option", "backend=9"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "backend" in bad.stderr
 
 
 def test_non_finite_geometry_does_not_hide_the_rest_of_the_scene(tracer, sky_small):
