@@ -182,7 +182,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                flattened.  Triangle tests still run on world-space vertices transformed as the shader transforms
  *                them, so the image does not change.  Host build time and device memory fall with the number of
  *                copies (38 copies of 262 k triangles: 4.0 s -> 0.09 s, 2.6 M -> 69 k nodes); tracing is slower
- *                (0.55x - 0.73x there).  Four-child tree and scheduled kernel only: "bvh_width" 2 flattens, other
+ *                (0.55x - 0.75x there).  Four-child tree and scheduled kernel only: "bvh_width" 2 flattens, other
  *                backends fall back to the scheduled kernel.  pt_update_transforms rebuilds the top-level tree on
  *                the host and uploads the scene again (12 ms there); the shared trees are kept until pt_set_meshes
  *                or until the scene outgrows the padding they were built with.

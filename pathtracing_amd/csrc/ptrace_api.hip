@@ -469,7 +469,13 @@ int rebuild_scene(pt_context *ctx)
     if (nP) diag = std::sqrt((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) +
                              (shi[2] - slo[2]) * (shi[2] - slo[2]));
     if (!std::isfinite(diag)) diag = 0.0f;
-    const float pad = 1e-5f * diag + 1e-6f;
+    // A general margin under the specific ones below (a triangle's own fuzz, the spheres' slack, the relative term for the slab
+    // arithmetic): about what a well-shaped triangle's own fuzz comes to.  It was 1e-5 * diag; rays that graze a tessellated
+    // floor then cross the margin of every triangle on their way, and on the 10 M-triangle scene (diag 600) that cost 6 % of
+    // the rays per second flattened and 20 % two-level.  With a hundredth of the old value (PTRACE_PAD_SCALE=0.0333 on this
+    // one) the benchmark scenes still render bit-identical images and a million soak frames still match the exhaustive loop.
+    float pad = 3e-6f * diag + 1e-6f;
+    if (const char *env = std::getenv("PTRACE_PAD_SCALE")) pad *= std::max(0.0f, (float)std::atof(env));      // measurement knob
     // IntersectSphere (SH:170-190) decides hit or miss by the sign of p1*p1 - dot(d,d) + r*r with d = origin - centre:
     // a difference of squares of the ray's distance to the sphere, so rounding lets it accept rays that pass up to
     // sqrt(r*r + k*eps*|d|^2) from the centre (for r = 0 that is |d| * 7e-4, far more than `pad`).  The box must hold
