@@ -181,11 +181,11 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                object; sheared or unevenly scaled objects, meshes used once and meshes under 64 triangles stay
  *                flattened.  Triangle tests still run on world-space vertices transformed as the shader transforms
  *                them, so the image does not change.  Host build time and device memory fall with the number of
- *                copies (38 copies of 262 k triangles: 4.0 s -> 0.09 s, 2.6 M -> 69 k nodes); tracing is slower
+ *                copies (38 copies of 262 k triangles: 4.1 s -> 0.08 s, 2.6 M -> 69 k nodes); tracing is slower
  *                (0.55x - 0.75x there).  Four-child tree and scheduled kernel only: "bvh_width" 2 flattens, other
  *                backends fall back to the scheduled kernel.  pt_update_transforms rebuilds the top-level tree on
- *                the host and uploads the scene again (12 ms there); the shared trees are kept until pt_set_meshes
- *                or until the scene outgrows the padding they were built with.
+ *                the host and sends it and the instance table (1.2 ms there); the shared trees stay, on the host and
+ *                on the device, until pt_set_meshes or until the scene outgrows the padding they were built with.
  *   "split_percent"  30 (default): before the tree is built, triangles that span a sixteenth of the scene or more are cut
  *                into several references (boxes holding a part of the triangle each; a leaf still names the whole
  *                triangle), at most this many additional references per hundred triangles of the scene; 0: none.  A

@@ -226,7 +226,7 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
         w.child[0] = encode_leaf(tmp[root].first, tmp[root].count);
         for (int k = 1; k < 4; k++) {
             for (int a = 0; a < 3; a++) { w.qlo[a][k] = 255; w.qhi[a][k] = 0; }
-            w.child[k] = w.child[0];
+            w.child[k] = encode_leaf((uint32_t)boxes.size(), 1);
         }
         out.nodes4.push_back(w);
         out.depth4 = 1;
@@ -311,8 +311,9 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
             nd.child[k] = c.count ? encode_leaf(c.first, c.count) : 0;
         }
         // An unused slot holds an inside-out box (low plane 255, high plane 0 on every axis), which no ray
-        // enters, so traversal needs no validity test.  Should rounding ever make such a box pass the slab
-        // test, its link repeats a sibling (set below), which costs time but cannot change the closest hit.
+        // enters, so traversal needs no validity test.  A ray with a wide margin on its box tests (far_slack in
+        // pt_device.hpp) can pass it all the same: the slot's link (set below) is a leaf of one record, the one past the
+        // last primitive, which the caller fills with zeros - a triangle without extent that nothing hits.
         for (int k = nk; k < 4; k++)
             for (int a = 0; a < 3; a++) { nd.qlo[a][k] = 255; nd.qhi[a][k] = 0; }
         out.nodes4.push_back(nd);
@@ -322,13 +323,9 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
         for (int k = nk - 1; k >= 0; k--)
             if (!tmp[kids[k]].count) st4.push_back({kids[k], me, k, it.depth + 1, it.stacked + nk - 1});
     }
-    for (Bvh4Node &nd : out.nodes4) {
-        int32_t spare = nd.child[0];
+    for (Bvh4Node &nd : out.nodes4)
         for (int k = 0; k < 4; k++)
-            if (((nd.valid >> k) & 1) && nd.child[k] < 0) { spare = nd.child[k]; break; }   // prefer a leaf
-        for (int k = 0; k < 4; k++)
-            if (!((nd.valid >> k) & 1)) nd.child[k] = spare;
-    }
+            if (!((nd.valid >> k) & 1)) nd.child[k] = encode_leaf((uint32_t)boxes.size(), 1);
     return out;
 }
 

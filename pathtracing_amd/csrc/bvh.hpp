@@ -40,7 +40,8 @@ constexpr int kMaxDepth = 60;      // traversal stack capacity bounds the depth
 // Wide device node, 64 bytes (56 used): four children whose boxes are quantised to 8 bits per plane
 // on a per-node grid (origin + power-of-two cell per axis), rounded outwards so a quantised box
 // always contains the exact one.  A slot without a child (valid bit clear) holds the inside-out box
-// qlo = 255, qhi = 0, which the slab test rejects by itself, and a sibling's link.
+// qlo = 255, qhi = 0, which the slab test rejects by itself, and a link to a leaf of one record: record number
+// boxes.size(), one past the last primitive, which the caller provides filled with zeros (nothing hits it).
 //   q0 = (org.x, org.y, org.z, ex | ey << 8 | ez << 16 | valid << 24)    cell = 2^(e - 127)
 //   q1 = child[0..3]            same encoding as BvhNode's links
 //   q2 = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   one byte per child

@@ -26,6 +26,7 @@ struct SceneDev {
                                // NULL = the shader's hard-coded surface for every triangle (SH:250-253)
     int32_t sky_w, sky_h;
     int32_t n_nodes, n_prims, n_spheres;
+    int32_t n_top_records;     // records of the top-level tree: the first n_top_records entries of `prims`
     int32_t n_nodes4;          // four-wide nodes (the stride between the node arrays of a PT_NODES_SOA build)
     // two-level scenes (instances): NULL / 0 when every mesh object is flattened into world-space records
     const float4 *inst;        // 8 x float4 per instance: rows 0..2 of localToWorld (x = row . (v, 1)), rows 0..2 of its inverse,
@@ -35,6 +36,9 @@ struct SceneDev {
     const float *vertices;     // object-space positions, 3 floats per vertex (:106)
     const float *matrices;     // 16 floats per mesh object (:105)
     int32_t n_inst;
+    // rays that start farther from the scene than the boxes were padded for (far_reach): see intersect_far_spheres()
+    float centre[3], half_diag, far_reach;
+    float spheres_lo[3], spheres_hi[3];   // bounds of the spheres (centre -+ |radius|), inside-out without spheres
 };
 
 // How far outside a triangle the Moeller-Trumbore arithmetic (SH:192-230) can still report a hit.  Its barycentric
@@ -505,6 +509,39 @@ __device__ __forceinline__ void intersect_ground_plane(f3 o, f3 d, float &tbest,
 {
     float t = -o.y / d.y;
     if (t > 0 && t < tbest) { tbest = t; idbest = 0; }
+}
+
+// A ray that starts beyond far_reach meets every sphere directly, as the shader's loop does (SH:273-277), if it comes
+// anywhere near them: from a distance D IntersectSphere's difference of squares accepts rays that pass within
+// sqrt(r * r + 8 eps D * D) of a centre, about 7e-4 D beyond the sphere - too much to give every box of the tree.  The
+// tree still holds the spheres; finding one twice changes nothing.
+__device__ __forceinline__ void intersect_far_spheres(const SceneDev &sc, f3 o, f3 d, float &tbest, int32_t &idbest)
+{
+    if (sc.n_spheres == 0) return;
+    const float dx = o.x - sc.centre[0], dy = o.y - sc.centre[1], dz = o.z - sc.centre[2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz) + sc.half_diag;
+    if (!(dist > sc.far_reach)) return;
+    // the spheres' bounds, widened by what the spheres look wider by from there, against the ray (conservative slab test)
+    const float m = 7.5e-4f * dist + 1e-3f * sc.half_diag;
+    float tn = 0.0f, tf = PT_INF;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float inv = 1.0f / (pt_abs(dd[k]) < 1e-18f ? __builtin_copysignf(1e-18f, dd[k]) : dd[k]);
+        const float a = (sc.spheres_lo[k] - m - oo[k]) * inv, b = (sc.spheres_hi[k] + m - oo[k]) * inv;
+        tn = fmaxf(tn, fminf(a, b)); tf = fminf(tf, fmaxf(a, b));
+    }
+    if (!(tn <= tf * 1.0001f)) return;
+    for (int i = 0; i < sc.n_spheres; i++) {
+        const float4 c = sc.sphere_mat[(size_t)i * 4];      // (centre, radius)
+        const f3 q = pt_sub3(o, xyz(c));                    // SH:170-190
+        const float p1 = -pt_dot3(d, q);
+        const float p2sqr = p1 * p1 - pt_dot3(q, q) + c.w * c.w;
+        if (p2sqr < 0) continue;
+        const float p2 = pt_sqrt(p2sqr);
+        const float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
+        if (t > 0 && (t < tbest || (t == tbest && i + 1 < idbest))) { tbest = t; idbest = i + 1; }
+    }
 }
 
 // ------------------------------------------------------------------- shading
@@ -1209,6 +1246,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             if (new_ray) {
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
+                intersect_far_spheres(sc, o, d, tbest, idbest);
                 sp = 0;
                 cur_inst = -1;
                 node = sc.n_nodes ? 0 : kDoneNode;
@@ -1344,14 +1382,16 @@ __global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uin
     f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);
     float t = PT_INF; int32_t id = -1; uint32_t rec = 0, cn = 0, cp = 0;
     intersect_ground_plane(o, d, t, id);
+    intersect_far_spheres(sc, o, d, t, id);
     traverse<WIDE>(sc, o, d, t, id, rec, st, cn, cp);
     ids[i] = id; ts[i] = t;
 }
 
-// One thread per ray; every primitive in id order with the shader's strict
-// comparison (SH:262-285).  `by_id` maps id-1 -> record index.
-__global__ __launch_bounds__(kBlock) void trace_rays_brute_kernel(SceneDev sc, const uint32_t *by_id, const float *od, int n,
-                                                                   int32_t *ids, float *ts)
+// One thread per ray against every primitive, no tree: the exhaustive loop of the shader (SH:262-285), which keeps the
+// first of equally near hits in id order - what intersect_record's (t, id) rule keeps in any order.  The records of
+// the top level hold every flattened primitive (a triangle cut into several references several times: harmless);
+// the triangles of instances come from the reference's own buffers.
+__global__ __launch_bounds__(kBlock) void trace_rays_brute_kernel(SceneDev sc, const float *od, int n, int32_t *ids, float *ts)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1360,11 +1400,10 @@ __global__ __launch_bounds__(kBlock) void trace_rays_brute_kernel(SceneDev sc, c
     float t = PT_INF; int32_t id = -1;
     intersect_ground_plane(o, d, t, id);
     uint32_t rec = 0;
-    // intersect_record keeps the (t, id)-smallest hit, which is what the strict comparison keeps when the primitives
-    // come in id order - so the order of the two loops below does not matter
-    for (int k = 0; k < sc.n_prims; k++) {
-        const uint32_t slot = by_id[k];
-        if (slot != 0xffffffffu) intersect_prim(sc.prims, slot, o, d, t, id, rec);      // 0xffffffff: a triangle of an instance, below
+    for (int k = 0; k < sc.n_top_records; k++) {
+        const float4 *p = sc.prims + (size_t)k * 3;
+        const float4 a = p[0], b = p[1], c = p[2];
+        if (as_i(b.w) != 2) intersect_record(a, b, c, (uint32_t)k, o, d, t, id, rec);      // kind 2 stands for an instance, below
     }
     for (int ii = 0; ii < sc.n_inst; ii++) {
         const float4 meta = sc.inst[(size_t)ii * 8 + 6];

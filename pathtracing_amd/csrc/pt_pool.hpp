@@ -374,6 +374,7 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
             if (new_ray) {
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
+                intersect_far_spheres(sc, o, d, tbest, idbest);
                 int32_t node = sc.n_nodes ? 0 : kDoneNode;
                 c_rays++;
                 if (cached) {                       // nothing to traverse: straight back to the shade queue

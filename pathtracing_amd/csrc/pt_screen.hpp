@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const RenderArgs a, int
         camera_ray(a, x, y, o, d);
         float t = PT_INF; int32_t id = -1; uint32_t rec = 0;
         intersect_ground_plane(o, d, t, id);
+        intersect_far_spheres(a.sc, o, d, t, id);
         traverse<WIDE>(a.sc, o, d, t, id, rec, st, cn, cp);
         rays++;
         if (what == 1 || what == 3) {

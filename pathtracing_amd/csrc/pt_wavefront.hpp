@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void wf_trace(const RenderArgs a)
                 o = xyz(ro); d = xyz(rd);
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
+                intersect_far_spheres(sc, o, d, tbest, idbest);
                 rsl = ray_slabs(o, d);
                 sp = 0;
                 node = sc.n_nodes ? 0 : kDoneNode;

@@ -28,6 +28,7 @@ using namespace ptrace;
 // built with still covers what a build asks for.
 struct CachedMesh {
     int32_t indices_offset = 0, indices_count = 0, leaf_size = 0;
+    uint64_t version = 0;                 // a new number with every build of this tree: what the device copy is checked against
     float pad = 0.0f, reach = 0.0f;       // object-space box padding and intersection reach the boxes were made for
     BvhResult bvh;
     std::vector<float4> recs;             // (v0, triangle index within the mesh) (v1, 0) (v2, 0) in tree order
@@ -80,11 +81,11 @@ struct pt_context {
     // device scene
     uint4 *d_nodes4 = nullptr;
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_sphere_mat = nullptr, *d_sky = nullptr;
-    uint32_t *d_by_id = nullptr;
     int n_nodes4 = 0, bvh_width = 4;
     int stack_need4 = 0;                           // most stack entries a ray can hold in the four-wide tree of the last build
     int stack_limit = kStackLds + kStackOverflow;  // entries a lane's stack holds; PTRACE_STACK_LIMIT lowers it (tests of the fallback)
     int n_nodes = 0, n_prims = 0, n_spheres = 0, sky_w = 0, sky_h = 0;
+    int n_top_records = 0;            // records of the top-level tree (n_slots plus one per instance)
     int n_slots = 0;                  // primitive records on the device: n_prims plus the extra references of split triangles
     float split_budget = 0.3f;        // option "split_percent": additional references, per triangle of the scene, the build may spend on large triangles
     float *d_slot_clip = nullptr;     // per slot, the unpadded box of its reference (only when some triangle was split)
@@ -96,6 +97,11 @@ struct pt_context {
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
     float4 *d_inst = nullptr;         // SceneDev::inst
     std::vector<CachedMesh> mesh_cache;
+    uint64_t mesh_versions = 0;
+    // Device layout of a two-level scene: [top-level nodes, room for inst_node_cap | mesh trees] and the same for the records, so
+    // that a build which finds the mesh trees of inst_sig already on the device sends the top level only.
+    size_t inst_node_cap = 0, inst_rec_cap = 0;
+    std::vector<uint64_t> inst_sig;
     int4 *d_objects = nullptr;        // SceneDev::objects
     int32_t *d_indices = nullptr;     // SceneDev::indices
 
@@ -566,6 +572,7 @@ int rebuild_scene(pt_context *ctx)
         if (!hit) { ctx->mesh_cache.emplace_back(); hit = &ctx->mesh_cache.back(); }
         CachedMesh &mt = *hit;
         mt.indices_offset = g.indices_offset; mt.indices_count = g.indices_count; mt.leaf_size = leaf_size;
+        mt.version = ++ctx->mesh_versions;
         const float pad_o = 1.1f * pad_need, reach_o = 1.25f * reach_need;      // wider boxes cost rays: 1.5 x the padding is 20 % fewer rays per second
         mt.pad = pad_o; mt.reach = reach_o;
         std::vector<Aabb> ob(n);
@@ -586,7 +593,7 @@ int rebuild_scene(pt_context *ctx)
         }
         mt.bvh = build_bvh(ob, leaf_size, 0, ct);
         mt.bvh.nodes.clear(); mt.bvh.nodes.shrink_to_fit();      // the two-child tree is not used for instances
-        mt.recs.resize(n * 3);
+        mt.recs.assign((n + 1) * 3, make_float4(0, 0, 0, 0));      // the last record stays zero (see rec_cap below)
         for (size_t slot = 0; slot < n; slot++) {
             const uint32_t t = mt.bvh.order[slot];
             const int32_t *ix = &ctx->indices[(size_t)g.indices_offset + 3 * t];
@@ -633,11 +640,18 @@ int rebuild_scene(pt_context *ctx)
         bvh.stack_need4 = need;
     }
 
-    size_t n_recs = nRefs;                                 // records on the device: the top level's, then every mesh tree's
+    // records on the device: the top level's (in two-level scenes with room to grow), then every mesh tree's
+    std::vector<uint64_t> sig;
+    for (const MeshTree *mt : mesh_trees) sig.push_back(mt->version);
+    const bool keep_mesh_trees = nI && sig == ctx->inst_sig && bvh.nodes4.size() <= ctx->inst_node_cap && nRefs < ctx->inst_rec_cap &&
+                                 ctx->d_nodes4 && ctx->d_prims;
+    const size_t node_cap = !nI ? bvh.nodes4.size() : keep_mesh_trees ? ctx->inst_node_cap : std::max<size_t>(256, 2 * bvh.nodes4.size());
+    // + 1: the record after the last one is all zeros, a triangle nothing hits - where the links of unused node slots point (bvh.hpp)
+    const size_t rec_cap = !nI ? nRefs + 1 : keep_mesh_trees ? ctx->inst_rec_cap : std::max<size_t>(256, 2 * (nRefs + 1));
+    size_t n_recs = rec_cap;
     for (const MeshTree *mt : mesh_trees) n_recs += mt->recs.size() / 3;
     if (n_recs >= (1u << 27)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^27 primitive records");
-    std::vector<float4> recs(n_recs * 3);
-    std::vector<uint32_t> by_id(nIds, 0xffffffffu);
+    std::vector<float4> recs((keep_mesh_trees ? nRefs + 1 : n_recs) * 3, make_float4(0, 0, 0, 0));
     for (size_t slot = 0; slot < nRefs; slot++) {
         uint32_t prim = ref_prim[bvh.order[slot]];
         if (prim >= nP) {                                  // an instance: kind 2, b.x = its index
@@ -649,7 +663,6 @@ int rebuild_scene(pt_context *ctx)
             continue;
         }
         int32_t id = (int)prim < nS ? 1 + (int32_t)prim : 1 + nS + (int32_t)tri_gid[prim - nS];
-        by_id[(size_t)id - 1] = (uint32_t)slot;
         float idf; std::memcpy(&idf, &id, 4);
         if ((int)prim < nS) {
             const PtSphere &s = ctx->spheres[prim];
@@ -670,7 +683,7 @@ int rebuild_scene(pt_context *ctx)
         // a top-level leaf that holds one instance and nothing else: its parent links to the instance itself
         for (Bvh4Node &nd : bvh.nodes4)
             for (int k = 0; k < 4; k++) {
-                if (nd.child[k] >= 0) continue;
+                if (nd.child[k] >= 0 || !((nd.valid >> k) & 1)) continue;      // an unused slot links to the record past the last one
                 const uint32_t enc = (uint32_t)~nd.child[k];
                 if ((enc & 7u) != 0) continue;
                 const uint32_t prim = ref_prim[bvh.order[enc >> 3]];
@@ -688,14 +701,21 @@ int rebuild_scene(pt_context *ctx)
     int rc;
     // ---- two-level scenes: the mesh trees follow the top-level tree in the node and record arrays; instance table
     ctx->n_inst = (int)nI;
-    free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices);
+    size_t real_nodes4 = bvh.nodes4.size();                // without the room left after the top level of a two-level scene
+    free_dev(ctx->d_inst); free_dev(ctx->d_objects);
+    if (!keep_mesh_trees) free_dev(ctx->d_indices);
     if (nI) {
         std::vector<uint32_t> group_root(groups.size());
-        size_t rec_base = nRefs;
+        size_t rec_base = rec_cap, node_next = node_cap;
+        const size_t top_nodes = bvh.nodes4.size();
+        if (!keep_mesh_trees) bvh.nodes4.resize(node_cap, Bvh4Node{});        // the room between the top level and the mesh trees
         for (size_t gi = 0; gi < groups.size(); gi++) {
             const MeshTree &mt = *mesh_trees[gi];
-            const uint32_t node_base = (uint32_t)bvh.nodes4.size();
+            const uint32_t node_base = (uint32_t)node_next;
             group_root[gi] = node_base;
+            node_next += mt.bvh.nodes4.size();
+            bvh.depth4 = std::max(bvh.depth4, mt.bvh.depth4);
+            if (keep_mesh_trees) { rec_base += mt.recs.size() / 3; continue; }
             for (Bvh4Node nd : mt.bvh.nodes4) {
                 for (int k = 0; k < 4; k++) {
                     if (nd.child[k] >= 0) nd.child[k] += (int32_t)node_base;
@@ -705,8 +725,8 @@ int rebuild_scene(pt_context *ctx)
             }
             std::copy(mt.recs.begin(), mt.recs.end(), recs.begin() + rec_base * 3);
             rec_base += mt.recs.size() / 3;
-            bvh.depth4 = std::max(bvh.depth4, mt.bvh.depth4);
         }
+        real_nodes4 = top_nodes + (node_next - node_cap);
         std::vector<float4> inst(nI * 8, make_float4(0, 0, 0, 0));
         for (size_t ii = 0; ii < nI; ii++) {
             const int o = inst_object[ii];
@@ -726,12 +746,16 @@ int rebuild_scene(pt_context *ctx)
         otab[ctx->objects.size()] = make_int4((int)nt, 0, 0, 0);
         if ((rc = upload(ctx, ctx->d_inst, inst.data(), inst.size() * sizeof(float4)))) return rc;
         if ((rc = upload(ctx, ctx->d_objects, otab.data(), otab.size() * sizeof(int4)))) return rc;
-        if ((rc = upload(ctx, ctx->d_indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t)))) return rc;
         std::vector<float> mats(ctx->objects.size() * 16);
         for (size_t o = 0; o < ctx->objects.size(); o++) std::memcpy(&mats[o * 16], ctx->objects[o].local_to_world, 64);
-        if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
+        if (!keep_mesh_trees || !ctx->d_indices || !ctx->d_vertices) {        // geometry: unchanged while the mesh trees are
+            if ((rc = upload(ctx, ctx->d_indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t)))) return rc;
+            if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
+        }
         if ((rc = upload(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)))) return rc;
     }
+    ctx->inst_sig = nI ? sig : std::vector<uint64_t>();
+    ctx->inst_node_cap = nI ? node_cap : 0; ctx->inst_rec_cap = nI ? rec_cap : 0;
     // ---- what a later refit needs: per slot its source triangle, the object-space vertices, the tree's levels
     ctx->refit_ready = false;
     if (ctx->refit && !bvh.nodes4.empty() && nI == 0) {
@@ -783,7 +807,13 @@ int rebuild_scene(pt_context *ctx)
         ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
         ctx->refit_ready = !ctx->objects.empty();
     }
-    if ((rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;
+    if (keep_mesh_trees) {
+        // the mesh trees and their records stay where they are: only the top level goes to the device
+        if ((rc = h2d(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
+        if ((rc = h2d(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
+    }
+    if (!nI && (rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;   // a two-level scene is never walked as a two-child tree
+    if (nI) free_dev(ctx->d_nodes);
 #ifdef PT_NODES_SOA
     {
         const size_t n4 = bvh.nodes4.size();
@@ -794,15 +824,15 @@ int rebuild_scene(pt_context *ctx)
         ctx->refit_ready = false;          // the refit kernels write whole records
     }
 #else
-    if ((rc = upload(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
+    if (!keep_mesh_trees && (rc = upload(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
 #endif
-    ctx->n_nodes4 = (int)bvh.nodes4.size();
-    if ((rc = upload(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
-    if ((rc = upload(ctx, ctx->d_by_id, by_id.data(), by_id.size() * sizeof(uint32_t)))) return rc;
+    ctx->n_nodes4 = (int)real_nodes4;
+    if (!keep_mesh_trees && (rc = upload(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
     if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
     ctx->n_nodes = (int)bvh.nodes.size();
     ctx->n_prims = (int)nIds;
     ctx->n_slots = (int)nR;
+    ctx->n_top_records = (int)nRefs;
     ctx->n_spheres = nS;
     ctx->stack_need4 = bvh.stack_need4;
     static_assert(kMaxDepth + 1 <= kStackLds + kStackOverflow, "the two-child tree must always fit the traversal stack");
@@ -812,7 +842,7 @@ int rebuild_scene(pt_context *ctx)
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING"))
-        std::fprintf(stderr, "scene build: %zu primitives, %zu references, %zu instances, %zu nodes; prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n", nIds, nR, nI, bvh.nodes4.size(),
+        std::fprintf(stderr, "scene build: %zu primitives, %zu references, %zu instances, %zu nodes%s; prepare %.1f ms, tree %.1f ms, pack + upload %.1f ms\n", nIds, nR, nI, real_nodes4, keep_mesh_trees ? " (mesh trees kept on the device)" : "",
                      std::chrono::duration<float, std::milli>(t_prep - t0).count(), std::chrono::duration<float, std::milli>(t_built - t_prep).count(),
                      std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_built).count());
     ctx->scene_dirty = false;
@@ -864,7 +894,12 @@ SceneDev scene_dev(const pt_context *ctx)
     sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
     sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres; sc.n_nodes4 = ctx->n_nodes4;
     sc.inst = ctx->d_inst; sc.objects = ctx->d_objects; sc.indices = ctx->d_indices; sc.vertices = ctx->d_vertices; sc.matrices = ctx->d_matrices;
-    sc.n_inst = ctx->n_inst;
+    sc.n_inst = ctx->n_inst; sc.n_top_records = ctx->n_top_records;
+    float half = 0.0f;
+    for (int k = 0; k < 3; k++) { sc.centre[k] = 0.5f * (ctx->scene_lo[k] + ctx->scene_hi[k]); const float e = ctx->scene_hi[k] - ctx->scene_lo[k]; half += e * e; }
+    sc.half_diag = 0.5f * std::sqrt(half);
+    sc.far_reach = ctx->sphere_reach;
+    for (int k = 0; k < 3; k++) { sc.spheres_lo[k] = ctx->spheres_lo[k]; sc.spheres_hi[k] = ctx->spheres_hi[k]; }
     return sc;
 }
 
@@ -1071,7 +1106,7 @@ void pt_destroy(pt_context *ctx)
     // renders may still be running on the caller's stream (pt_set_stream): they use the buffers freed below
     if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky); free_dev(ctx->d_by_id);
+    free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds); free_dev(ctx->own_display);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
@@ -1796,7 +1831,7 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) { cleanup(); return rc; }
     SceneDev sc = scene_dev(ctx);
     if (brute_force)
-        hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
+        hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_od, n_rays, d_id, d_t);
     else if (tree_width(ctx) == 4)
         hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     else
@@ -1835,7 +1870,7 @@ int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
     PT_HIP(ctx, hipMemcpyAsync(d_od, origins_dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice, ctx->stream));
     const SceneDev sc = scene_dev(ctx);
     if (brute_force)
-        hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_by_id, d_od, n_rays, d_id, d_t);
+        hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_od, n_rays, d_id, d_t);
     else if (tree_width(ctx) == 4)
         hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_stack, d_od, n_rays, d_id, d_t);
     else

@@ -308,3 +308,40 @@ def test_new_targets_are_zero_before_the_next_frame_reads_them():
             sevens = np.full((H, W, 4), 7.0, np.float32)
             for which in (pa.PT_TARGET_RESULT, pa.PT_TARGET_CONVERGED, pa.PT_TARGET_DENOISED):
                 t.write_target(which, sevens)
+
+
+@pytest.mark.parametrize("width", [4, 2])
+def test_spheres_seen_from_far_out_on_the_ground_plane(width):
+    """tools/soak_params.py 200 20261111, dispatch 153 608: a camera 40 above the ground with a 175 degree field of view
+    sees the plane 4 215 units away; a path that bounces there looks back at the spheres from a distance at which
+    IntersectSphere's difference of squares (RayTracingShader.compute:170-190) accepts rays passing units beside a sphere -
+    the exhaustive loop reports such a hit, the tree, whose sphere boxes are padded for origins near the scene, did not.
+    Rays that start beyond that reach now meet the spheres directly (intersect_far_spheres)."""
+    s = pa.Scene("xr"); sky = pa.procedural_sky(64, 32)
+    W, H = 64, 5
+    p = pa.make_params(s, W, H, seed=0.6286261677742004, spp=3, max_bounces=4, fov=175.0,
+                       eye=(-4.565361642855158, 40.0, -6.131743939305356), target=(0.8743084992982872, -1.919203517003022, -1.7489561927078008))
+    c, cid, cst = po.Oracle.from_scene(s, sky, accel=False).render(p, W, H, threads=4)
+    assert c[2, 12, 3] > 4000.0                                   # the pixel whose path comes back from far out
+    with pa.PathTracer(0) as t:
+        t.set_option("bvh_width", width)
+        for backend in (0, 1, 2):
+            t.set_option("backend", backend)
+            t.load_scene(s, sky); t.resize(W, H)
+            t.render(p)
+            g = t.read_result()
+            assert (t.read_hit_ids() == cid).all() and _same(g, c), (width, backend, np.argwhere(~_same_px(g, c))[:4])
+        # the ray queries take the same route
+        rng = np.random.default_rng(3)
+        o = np.zeros((2000, 3), np.float32); o[:, 0] = rng.uniform(500, 6000, 2000) * rng.choice([-1, 1], 2000); o[:, 1] = rng.uniform(0.001, 3.0, 2000)
+        o[:, 2] = rng.uniform(-3000, 3000, 2000)
+        aim = rng.uniform(-6, 6, (2000, 3)).astype(np.float32); aim[:, 1] = rng.uniform(0.2, 4, 2000)
+        d = aim - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        od = np.concatenate([o, d.astype(np.float32)], 1)
+        ib, tb = t.trace_rays(od); ie, te = t.trace_rays(od, brute_force=True)
+        assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
+        assert (ib > 0).mean() > 0.02                                 # some of them do find a sphere or the cube
+
+
+def _same_px(a, b):
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(-1)

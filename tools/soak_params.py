@@ -33,8 +33,9 @@ def run(budget=60.0, seed=1):
     while time.time() - t0 < budget:
         name = str(rng.choice(list(scenes))); s = scenes[name]; o = oracles[name]
         W = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 33, 64, 65, int(rng.integers(1, 90))])); H = int(rng.choice([1, 2, 5, 8, 17, 36, int(rng.integers(1, 70))]))
-        t.set_option("bvh_width", int(rng.choice([2, 4])))
-        t.set_option("reuse_primary_hit", int(rng.random() < 0.2))
+        width = int(rng.choice([2, 4])); reuse = int(rng.random() < 0.2)
+        t.set_option("bvh_width", width)
+        t.set_option("reuse_primary_hit", reuse)
         if current != name:
             t.load_scene(s, sky); current = name
         t.resize(W, H)
@@ -57,7 +58,7 @@ def run(budget=60.0, seed=1):
             acc = pa.PT_ACCUM_NONE
         p = pa.make_params(s, W, H, seed=float(rng.choice([0.0, 1.0, rng.random(), 123.456])), spp=int(rng.choice([0, 1, 1, 2, 3])),
                            max_bounces=int(rng.choice([1, 2, 4, 8, 50])), depth=depth, accumulate=acc, sample_index=sidx, tile=tile,
-                           eye=tuple(eye), target=tuple(target), fov=float(rng.choice([1.0, 30.0, 60.0, 120.0, 175.0])))
+                           eye=tuple(eye), target=tuple(target), fov=(fov := float(rng.choice([1.0, 30.0, 60.0, 120.0, 175.0]))))
         t.render(p)
         g, gc, gid = t.read_result(), t.read_converged(), t.read_hit_ids()
         c, cid, _ = o.render(p, W, H, threads=4, out=marker.copy())
@@ -75,7 +76,8 @@ def run(budget=60.0, seed=1):
             ok = ok and (gid[inside] == cid[inside]).all()
         if not ok:
             print("MISMATCH after", n, ":", name, W, H, "tile", tile, "acc", acc, "sample_index", sidx, "depth", depth, "spp", p.samples_per_pixel,
-                  "bounces", p.max_bounces, "eye", eye.tolist(), "target", list(map(float, target)), "seed", p.seed, flush=True)
+                  "bounces", p.max_bounces, "eye", eye.tolist(), "target", list(map(float, target)), "seed", p.seed, "fov", fov, "bvh_width", width,
+                  "reuse_primary_hit", reuse, flush=True)
             print("  result same", same(g, c), "converged same", same(gc, want_conv), flush=True)
             bad = np.argwhere(~((g.view(np.uint32) == c.view(np.uint32)) | (np.isnan(g) & np.isnan(c))).all(-1))
             for y, x in bad[:4]:
