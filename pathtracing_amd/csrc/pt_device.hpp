@@ -271,7 +271,7 @@ __device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v 
 
 template <class ST>
 __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
-                                              const ST &st, int &sp)
+                                              const ST &st, int &sp, uint32_t *empty = nullptr)
 {
 #ifdef PT_NODES_SOA
     // measurement build: the same nodes as four arrays of 16-byte columns (origin + exponents | links | low planes and
@@ -287,9 +287,10 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
 #endif
     const uint32_t meta = q0.w;
     // plane position along the ray: ((org + k * cell) - o) * inv = k * (cell * inv) + (org - o) * inv
-    const float sx = __uint_as_float((meta & 0xffu) << 23) * r.ix;
-    const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * r.iy;
-    const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * r.iz;
+    // cell * inv: the reciprocal direction scaled by the cell's power of two (one byte-select-and-add, one ldexp per axis)
+    const float sx = __builtin_ldexpf(r.ix, (int)(meta & 0xffu) - 127);
+    const float sy = __builtin_ldexpf(r.iy, (int)((meta >> 8) & 0xffu) - 127);
+    const float sz = __builtin_ldexpf(r.iz, (int)((meta >> 16) & 0xffu) - 127);
     const float bx = __builtin_fmaf(__uint_as_float(q0.x), r.ix, r.ox);
     const float by = __builtin_fmaf(__uint_as_float(q0.y), r.iy, r.oy);
     const float bz = __builtin_fmaf(__uint_as_float(q0.z), r.iz, r.oz);
@@ -306,19 +307,17 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
         float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
         float tf = fminf(fminf(fx, fy), fz);
         bool hit = tn <= tf * 1.000002f && tn <= tbest;   // an unused slot holds an inside-out box: never entered
-        // entry distance (>= 0, so its bits order like an unsigned) with the child slot in the low bits
-        key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xffffffffu;
+        key[c] = hit ? __float_as_uint(tn) : 0xffffffffu;   // entry distance (>= 0, so its bits order like an unsigned)
     }
-    // sorting network, ascending: nearest child first, misses last
-#define PT_CSWAP(i, j) { uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+    // sorting network over (distance, link) pairs, ascending: nearest child first, misses last.  Carrying the links through
+    // the five exchanges (a compare and four selects each) is cheaper than sorting keys with the slot in their low bits and
+    // picking each link out of the four afterwards (two tests and three selects per link): 17 vector instructions less.
+    uint32_t lnk[4] = {q1.x, q1.y, q1.z, q1.w};
+#define PT_CSWAP(i, j) { const bool s_ = key[j] < key[i]; const uint32_t ki_ = key[i], li_ = lnk[i]; \
+                         key[i] = s_ ? key[j] : ki_; lnk[i] = s_ ? lnk[j] : li_; key[j] = s_ ? ki_ : key[j]; lnk[j] = s_ ? li_ : lnk[j]; }
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
-    // child link of a sorted key, by selects (no branches): slot = key & 3
-    auto child_of = [&](uint32_t k) -> int32_t {
-        uint32_t lo = (k & 1u) ? q1.y : q1.x, hi = (k & 1u) ? q1.w : q1.z;
-        return (int32_t)((k & 2u) ? hi : lo);
-    };
-    const int32_t c0 = child_of(key[0]), c1 = child_of(key[1]), c2 = child_of(key[2]), c3 = child_of(key[3]);
+    const int32_t c0 = (int32_t)lnk[0], c1 = (int32_t)lnk[1], c2 = (int32_t)lnk[2], c3 = (int32_t)lnk[3];
     // children to stack: keys 1 .. hits-1, farthest first so that the nearest of them is popped first
     const int np = key[3] != 0xffffffffu ? 3 : key[2] != 0xffffffffu ? 2 : key[1] != 0xffffffffu ? 1 : 0;
     if (sp + 3 <= ST::kLds) {
@@ -334,6 +333,7 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
         if (np >= 2) stack_push(st, sp, c2);
         if (np >= 1) stack_push(st, sp, c1);
     }
+    if (empty && key[0] == 0xffffffffu) (*empty)++;
     if (key[0] == 0xffffffffu) return sp ? stack_pop(st, sp) : kDoneNode;
     return c0;
 }
@@ -1274,7 +1274,10 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // meanwhile, so only that one count is re-evaluated
             for (;;) {
                 if (node >= 0) {
-                    node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++;
+#ifdef PT_COUNT_EMPTY
+                    if constexpr (WIDE == 4) { uint32_t e_ = 0; node = node_step4(sc, node, rsl, tbest, st, sp, &e_); ray_work += e_; } else
+#endif
+                    { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++; }
                     if (INST) resolve_instance_links(sc, node, o, d, cur_inst, rsl, st, sp);
                 }
                 const int still = __popcll(__ballot(node >= 0));
