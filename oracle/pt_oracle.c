@@ -36,7 +36,7 @@ struct PtoPrepared {
     PtMaterial *materials; int32_t n_materials;   /* per mesh object; none = SH:250-253 for every triangle */
     float *sky; int32_t sky_w, sky_h;
     int accel;
-    ONode *nodes; int32_t n_nodes; int32_t *order; /* BVH over prim ids 1.. (spheres then tris) */
+    ONode *nodes; int32_t n_nodes; int32_t *order; /* BVH over the triangles' prim ids (n_spheres + 1 ..) */
 };
 
 typedef struct RngState { float seed; float px, py; } RngState;  /* _Seed, _Pixel  SH:47-48 */
@@ -172,14 +172,20 @@ static void intersect_tri(const Ray *ray, RayHit *best, const Tri *tr, int32_t i
 }
 
 /* The oracle's own acceleration structure (accel != 0): a median-split BVH
- * over spheres and triangles.  Not in the reference.  It prunes with padded
+ * over the triangles.  Not in the reference.  It prunes with padded
  * boxes and picks the winner by (distance, id) - the same winner the
- * exhaustive strict-less-than loop in id order picks. */
-static int box_hit(const ONode *n, const Ray *ray, f3 inv, float best)
+ * exhaustive strict-less-than loop in id order picks.
+ * What the boxes must not prune are the hits that only rounding produces: IntersectSphere (SH:170-190) decides by
+ * the sign of a difference of squares of the origin's distance D, so it accepts rays passing sqrt(r^2 + k eps D^2) from
+ * the centre - units beside a sphere for an origin some 10^4 units out on the ground plane - which is why the spheres
+ * (at most a few hundred) are not in the tree at all: trace() tests every one of them, as the shader does.  Moeller-
+ * Trumbore's barycentrics err by about 8 eps (L^2 / |e1 x e2|) max(L, D) in world units; `margin`, a distance the
+ * boxes are widened by for one ray, grows with the ray's distance from the scene to cover that. */
+static int box_hit(const ONode *n, const Ray *ray, f3 inv, float best, float margin)
 {
-    float tx0 = (n->lo[0] - ray->origin.x) * inv.x, tx1 = (n->hi[0] - ray->origin.x) * inv.x;
-    float ty0 = (n->lo[1] - ray->origin.y) * inv.y, ty1 = (n->hi[1] - ray->origin.y) * inv.y;
-    float tz0 = (n->lo[2] - ray->origin.z) * inv.z, tz1 = (n->hi[2] - ray->origin.z) * inv.z;
+    float tx0 = (n->lo[0] - margin - ray->origin.x) * inv.x, tx1 = (n->hi[0] + margin - ray->origin.x) * inv.x;
+    float ty0 = (n->lo[1] - margin - ray->origin.y) * inv.y, ty1 = (n->hi[1] + margin - ray->origin.y) * inv.y;
+    float tz0 = (n->lo[2] - margin - ray->origin.z) * inv.z, tz1 = (n->hi[2] + margin - ray->origin.z) * inv.z;
     float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
     return tmin <= tmax * 1.000002f + 1e-30f && tmin <= best;
@@ -194,17 +200,24 @@ static void trace_bvh(const PtoPrepared *p, const Ray *ray, RayHit *best, Counte
     if (fabsf(dd.y) < 1e-18f) dd.y = copysignf(1e-18f, dd.y);
     if (fabsf(dd.z) < 1e-18f) dd.z = copysignf(1e-18f, dd.z);
     f3 inv = pt_make3(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z);
+    /* the ray's distance from the farthest corner of the scene: 6.4e-6 of it is sixteen times a well-shaped
+     * triangle's reach at that distance; the boxes' own padding covers the near field */
+    const ONode *root = &p->nodes[0];
+    const float fx = fmaxf(fabsf(ray->origin.x - root->lo[0]), fabsf(ray->origin.x - root->hi[0]));
+    const float fy = fmaxf(fabsf(ray->origin.y - root->lo[1]), fabsf(ray->origin.y - root->hi[1]));
+    const float fz = fmaxf(fabsf(ray->origin.z - root->lo[2]), fabsf(ray->origin.z - root->hi[2]));
+    float margin = 6.4e-6f * sqrtf(fx * fx + fy * fy + fz * fz);
+    if (!(margin < 1e30f)) margin = 1e30f;        /* NaN or infinite origin: every box is entered */
     int32_t stack[128]; int sp = 0;
     stack[sp++] = 0;
     while (sp) {
         const ONode *n = &p->nodes[stack[--sp]];
-        if (!box_hit(n, ray, inv, best->distance)) continue;
+        if (!box_hit(n, ray, inv, best->distance, margin)) continue;
         if (n->count) {
             for (int32_t k = 0; k < n->count; k++) {
                 int32_t id = p->order[n->first + k];
                 cn->prims++;
-                if (id <= p->n_spheres) intersect_sphere(ray, best, &p->spheres[id - 1], id, 1);
-                else intersect_tri(ray, best, &p->tris[id - 1 - p->n_spheres], id, 1, p->materials);
+                intersect_tri(ray, best, &p->tris[id - 1 - p->n_spheres], id, 1, p->materials);
             }
         } else {
             stack[sp++] = n->left; stack[sp++] = n->right;
@@ -218,7 +231,13 @@ static RayHit trace(const PtoPrepared *p, const Ray *ray, Counters *cn)
     RayHit best = create_ray_hit();
     cn->trace_calls++;
     intersect_ground_plane(ray, &best);
-    if (p->accel) { trace_bvh(p, ray, &best, cn); return best; }
+    if (p->accel) {
+        for (int32_t i = 0; i < p->n_spheres; i++)
+            intersect_sphere(ray, &best, &p->spheres[i], 1 + i, 1);
+        cn->prims += (uint64_t)p->n_spheres;
+        trace_bvh(p, ray, &best, cn);
+        return best;
+    }
     for (int32_t i = 0; i < p->n_spheres; i++)
         intersect_sphere(ray, &best, &p->spheres[i], 1 + i, 0);
     /* mesh objects in order, triangles in order: p->tris is that flattened order */
@@ -1127,20 +1146,22 @@ PtoPrepared *pto_prepare(const PtoScene *sc, int accel)
         memcpy(p->sky, sc->sky, n * sizeof(float));
         p->sky_w = sc->sky_w; p->sky_h = sc->sky_h;
     }
+    /* the tree holds the triangles only (see box_hit); cent is indexed by prim id - 1, so it keeps the spheres' slots */
     int32_t np = p->n_spheres + p->n_tris;
-    if (accel && np > 0) {
-        p->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)np);
-        for (int32_t i = 0; i < np; i++) p->order[i] = i + 1;
-        p->nodes = (ONode *)malloc(sizeof(ONode) * (size_t)(2 * np));
+    if (accel && p->n_tris > 0) {
+        const int32_t nt = p->n_tris;
+        p->order = (int32_t *)malloc(sizeof(int32_t) * (size_t)nt);
+        for (int32_t i = 0; i < nt; i++) p->order[i] = p->n_spheres + i + 1;
+        p->nodes = (ONode *)malloc(sizeof(ONode) * (size_t)(2 * nt));
         float lo[3], hi[3], clo[3], chi[3];
-        node_bounds(p, p->order, np, lo, hi, clo, chi);
+        node_bounds(p, p->order, nt, lo, hi, clo, chi);
         float diag = sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
         float *cent = (float *)malloc(sizeof(float) * 3 * (size_t)np);
         for (int axis = 0; axis < 3; axis++)
-            for (int32_t i = 0; i < np; i++) cent[(size_t)axis * (size_t)np + i] = centroid(p, i + 1, axis);
+            for (int32_t i = p->n_spheres; i < np; i++) cent[(size_t)axis * (size_t)np + i] = centroid(p, i + 1, axis);
 #pragma omp parallel
 #pragma omp single
-        build_node(p, 0, np, 1e-5f * diag + 1e-6f, cent, np);
+        build_node(p, 0, nt, 1e-5f * diag + 1e-6f, cent, np);
         free(cent);
     }
     return p;

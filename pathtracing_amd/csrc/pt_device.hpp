@@ -333,7 +333,7 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
         if (np >= 2) stack_push(st, sp, c2);
         if (np >= 1) stack_push(st, sp, c1);
     }
-    if (empty && key[0] == 0xffffffffu) (*empty)++;
+    if (empty && key[0] == 0xffffffffu) (*empty)++;   // -DPT_COUNT_EMPTY only
     if (key[0] == 0xffffffffu) return sp ? stack_pop(st, sp) : kDoneNode;
     return c0;
 }
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // meanwhile, so only that one count is re-evaluated
             for (;;) {
                 if (node >= 0) {
-#ifdef PT_COUNT_EMPTY
+#ifdef PT_COUNT_EMPTY   // measurement build: the node statistic counts only the visits that entered no child
                     if constexpr (WIDE == 4) { uint32_t e_ = 0; node = node_step4(sc, node, rsl, tbest, st, sp, &e_); ray_work += e_; } else
 #endif
                     { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++; }

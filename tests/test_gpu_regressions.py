@@ -345,3 +345,40 @@ def test_spheres_seen_from_far_out_on_the_ground_plane(width):
 
 def _same_px(a, b):
     return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(-1)
+
+
+def test_frame_whose_camera_ray_meets_the_ground_plane_39_450_units_out(tracer):
+    """A frame a run of tools/soak_session.py recorded as a mismatch (seed 20261112, frame 90 767: scene xr, 48x47,
+    renderMode 2, 2 spp, 2 bounces, after 8 964 refits).  Pixel (28, 27) looks along the ground plane and meets it 39 450
+    units out; the bounce from there comes back past a sphere, several units beside it, and IntersectSphere's difference
+    of squares (RayTracingShader.compute:170-190) calls that a hit.  The exhaustive loop - the reference - shows it and so
+    did every kernel; the oracle's own tree had pruned it.  The oracle now tests every sphere for every ray; here the
+    frame must be the same on the device, in the exhaustive oracle and in the accelerated one."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "session_far_plane_frame.npz"))
+    W, H = int(z["W"]), int(z["H"])
+    p = pa.PtFrameParams.from_buffer_copy(z["params"].tobytes())
+    sz = C.sizeof(pa.PtCameraHistory)
+    old = [pa.PtCameraHistory.from_buffer_copy(z["cams"].tobytes()[i * sz:(i + 1) * sz]) for i in range(int(z["n_cams"]))]
+    cams = old + [pa.PtCameraHistory() for _ in range(100 - len(old))]
+    scene = pa.Scene(str(z["scene"])); sky = pa.procedural_sky(64, 32)
+    objs = z["objs"]
+    images = []
+    for accel in (False, True):
+        orc = po.Oracle(scene.spheres, objs, scene.vertices, scene.indices, sky=sky, accel=accel)
+        res, res1, res2 = [a.copy() for a in z["before"]]
+        orc.render_history(p, cams, W, H, res, res1, threads=4, result2=res2)
+        images.append((res, res1, res2))
+    for a, b in zip(*images):
+        assert _same(a, b)
+    assert images[0][0][27, 28, 3] > 39000.0          # the pixel in question: its primary hit lies that far out
+    t = tracer
+    t.load_scene(scene, sky)
+    t.update_transforms(objs)
+    t.resize(W, H)
+    t.write_target(pa.PT_TARGET_RESULT, z["before"][0]); t.write_converged(z["before"][1]); t.write_target(pa.PT_TARGET_DENOISED, z["before"][2])
+    t.clear_camera_history()
+    t.set_camera_history(old)
+    t.render(p)
+    for got, want in zip((t.read_result(), t.read_converged(), t.read_target(pa.PT_TARGET_DENOISED)), images[0]):
+        assert _same(got, want)

@@ -264,6 +264,35 @@ def test_oracle_bvh_equals_exhaustive_loop_random_rays_70k():
     assert (ia > len(s.spheres)).mean() > 0.3
 
 
+def test_oracle_bvh_keeps_the_sphere_hits_that_only_rounding_produces():
+    # IntersectSphere (SH:170-190) takes the sign of p1^2 - d.d + r^2, a difference of squares of the origin's distance:
+    # from 40 000 units out on the ground plane it accepts rays that pass several units beside a sphere.  The exhaustive
+    # loop reports those hits, so the oracle's tree must not prune them (a session soak found one such pixel).
+    s = pa.Scene("xr")
+    a = po.Oracle.from_scene(s, accel=False); b = po.Oracle.from_scene(s, accel=True)
+    rng = np.random.default_rng(5)
+    sph = np.asarray(s.spheres, np.float64)[:, :4]            # position, radius
+    rays = []
+    for c in sph:
+        for _ in range(200):
+            ang = rng.uniform(0, 2 * np.pi)
+            o = np.array([c[0] + 39450.0 * np.cos(ang), 1e-3, c[2] + 39450.0 * np.sin(ang)])
+            fuzz = np.sqrt(c[3] ** 2 + 16 * 6e-8 * 39450.0 ** 2)
+            tgt = c[:3] + rng.normal(size=3) * fuzz * 0.7
+            d = tgt - o; d /= np.linalg.norm(d)
+            rays.append(np.concatenate([o, d]))
+    od = np.array(rays, np.float32)
+    ia, ta = a.trace_rays(od); ib, tb = b.trace_rays(od)
+    assert (ia == ib).all() and (ta.view(np.uint32) == tb.view(np.uint32)).all()
+    # the case is present: sphere hits by rays whose distance from the centre (in float64) exceeds the radius by 1 % or more
+    hit = (ia >= 1) & (ia <= len(sph))
+    o64 = od[:, :3].astype(np.float64); d64 = od[:, 3:].astype(np.float64); d64 /= np.linalg.norm(d64, axis=1, keepdims=True)
+    cc = sph[np.clip(ia - 1, 0, len(sph) - 1)]
+    v = cc[:, :3] - o64
+    miss = np.linalg.norm(v - (v * d64).sum(1, keepdims=True) * d64, axis=1)
+    assert (hit & (miss > 1.01 * cc[:, 3])).sum() >= 20
+
+
 # -------------------------------------------------------------- accumulation
 
 def test_accumulate_matches_numpy_restatement():

@@ -17,6 +17,34 @@ from oracle import pt_oracle as po  # noqa: E402
 
 
 
+def diagnose(t, p, old, before, gpu, model, name, objs, W, H, frames):
+    """After a mismatch: keep the inputs, then render the frame again from the same targets - as it was, on the two-child
+    tree and on the other kernels - to tell a race from a wrong hit and a kernel from the tree."""
+    import ctypes
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.savez(os.path.join(ROOT, "gpurun_out", "soak_session_failure.npz"), params=np.frombuffer(ctypes.string_at(ctypes.byref(p), ctypes.sizeof(p)), np.uint8),
+             cams=np.frombuffer(b"".join(ctypes.string_at(ctypes.byref(c), ctypes.sizeof(c)) for c in old), np.uint8), n_cams=len(old),
+             objs=objs, scene=name, W=W, H=H, frame=frames, before=np.stack(before), gpu=np.stack(gpu), model=np.stack(model))
+
+    def again(label):
+        t.write_target(pa.PT_TARGET_RESULT, before[0]); t.write_converged(before[1]); t.write_target(pa.PT_TARGET_DENOISED, before[2])
+        t.set_camera_history(old)
+        t.render(p)
+        out = (t.read_result(), t.read_converged(), t.read_target(pa.PT_TARGET_DENOISED))
+        eq_first = all((a.view(np.uint32) == b.view(np.uint32)).all() for a, b in zip(out, gpu))
+        eq_model = all(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all() for a, b in zip(out, model))
+        print("  again,", label, ": equals the first GPU frame", eq_first, ", equals the model", eq_model, flush=True)
+
+    again("unchanged")
+    for key, val, label in (("bvh_width", 2, "two-child tree"), ("bvh_width", 4, "four-child tree again"), ("backend", 1, "wavefront stages"),
+                            ("backend", 2, "ray pool"), ("backend", 0, "scheduled kernel again")):
+        try:
+            t.set_option(key, val)
+            again(label)
+        except Exception as e:       # an option a build does not have must not hide the mismatch itself
+            print("  ", label, "not run:", e, flush=True)
+
+
 def run(budget=60.0, seed=1):
     """One soak of `budget` seconds from `seed`; raises AssertionError on the first mismatch, returns the count of checked items."""
     rng = np.random.default_rng(seed)
@@ -72,10 +100,12 @@ def run(budget=60.0, seed=1):
         # SetShaderParameters: upload the lists as they stand, then clear / extend them (:492-526)
         t.set_camera_history(old)
         cams[:len(old)] = old
+        old_uploaded = list(old)
         if mode < 5 or mode > 8 or p.counter == 0:
             old = []
         if mode < 11 and mode != 1:
             old = old + [pa.camera_history_entry(tuple(eye), tuple(scene.target), scene.fov, W / H)]
+        before = (res.copy(), res1.copy(), res2.copy())
         t.render(p)
         orc.render_history(p, cams, W, H, res, res1, threads=4, result2=res2)
         g = (t.read_result(), t.read_converged(), t.read_target(pa.PT_TARGET_DENOISED))
@@ -86,6 +116,7 @@ def run(budget=60.0, seed=1):
                       "depth", depth, "spp", p.samples_per_pixel, "pixels", len(bad), "first", bad[:3].tolist(), events, flush=True)
                 for y, x in bad[:3]:
                     print("  ", (int(x), int(y)), "gpu", a[y, x], "model", b[y, x], flush=True)
+                diagnose(t, p, old_uploaded, before, g, (res, res1, res2), name, objs, W, H, frames)
                 raise AssertionError("soak mismatch (details printed above)")
         frames += 1
         lit += int((res[..., :3] > 0).mean() > 0.5)
