@@ -140,6 +140,9 @@ constexpr int kDoneNode = (int)0x80000000;   // traversal state "stack empty: ra
 constexpr uint32_t kInstanceBit = 0x40000000u;
 constexpr int kExitInstance = (int)0x80000007;   // between the lane states below and the smallest leaf link
 
+#ifndef PT_STACK_T
+#define PT_STACK_T 0
+#endif
 __device__ __forceinline__ float as_f(int32_t i) { return __int_as_float(i); }
 __device__ __forceinline__ int32_t as_i(float f) { return __float_as_int(f); }
 __device__ __forceinline__ f3 xyz(float4 q) { return pt_make3(q.x, q.y, q.z); }
@@ -150,20 +153,25 @@ __device__ __forceinline__ f3 xyz(float4 q) { return pt_make3(q.x, q.y, q.z); }
 // thread t at lds[e * kBlock + t]: consecutive lanes hit consecutive banks), deeper
 // entries in a global overflow buffer laid out [entry][global thread] so that a
 // wave's accesses coalesce.  bvh.hpp's kMaxDepth bounds the total.
-template <int LDS_ENTRIES, int LDS_STRIDE>
+// WITH_T: the entries in LDS also keep the distance at which the ray enters their box (lds_t, same layout), so that a
+// popped entry that lies beyond the hit found meanwhile is dropped without a visit; entries in the overflow buffer carry
+// no distance and are always visited.
+template <int LDS_ENTRIES, int LDS_STRIDE, bool WITH_T = false>
 struct StackT {
     uint32_t *lds;        // entry 0 of this lane's stack; entry e lies LDS_STRIDE words further per entry
     uint32_t *overflow;   // entry LDS_ENTRIES of this lane's stack in the global buffer
     uint32_t stride;      // words between consecutive overflow entries (stacks in the grid)
+    uint32_t *lds_t;      // WITH_T: the entry distances' bits
     static constexpr int kLds = LDS_ENTRIES, kStride = LDS_STRIDE;
-    static constexpr int kCapacity = kStackLds + kStackOverflow;
+    static constexpr bool kWithT = WITH_T;
+    static constexpr int kCapacity = WITH_T ? LDS_ENTRIES + kStackOverflow : kStackLds + kStackOverflow;
 };
 typedef StackT<kStackLds, kBlock> Stack;   // one stack per thread of a kBlock-thread block: &lds_stack[threadIdx.x], &overflow[global thread id]
 
 template <class ST>
-__device__ __forceinline__ void stack_push(const ST &s, int &sp, int32_t v)
+__device__ __forceinline__ void stack_push(const ST &s, int &sp, int32_t v, uint32_t tbits = 0)
 {
-    if (sp < ST::kLds) s.lds[sp * ST::kStride] = (uint32_t)v;
+    if (sp < ST::kLds) { s.lds[sp * ST::kStride] = (uint32_t)v; if constexpr (ST::kWithT) s.lds_t[sp * ST::kStride] = tbits; }
     else if (sp < ST::kCapacity) s.overflow[(size_t)(sp - ST::kLds) * s.stride] = (uint32_t)v;
     sp++;  // beyond capacity the entry would be dropped; the host never launches on a tree that can get there
 }
@@ -174,6 +182,26 @@ __device__ __forceinline__ int32_t stack_pop(const ST &s, int &sp)
     if (sp < ST::kLds) return (int32_t)s.lds[sp * ST::kStride];
     if (sp < ST::kCapacity) return (int32_t)s.overflow[(size_t)(sp - ST::kLds) * s.stride];
     return 0;
+}
+// The next stacked node the ray still has to visit, or kDoneNode: with distances on the stack, entries whose box the ray
+// enters beyond `tbest` are skipped (strictly beyond: an equally near hit with a smaller id must still be found).
+template <class ST>
+__device__ __forceinline__ int32_t stack_next(const ST &s, int &sp, float tbest)
+{
+    if constexpr (ST::kWithT) {
+        while (sp) {
+            sp--;
+            if (sp < ST::kLds) {
+                const int32_t v = (int32_t)s.lds[sp * ST::kStride];
+                if (!(__uint_as_float(s.lds_t[sp * ST::kStride]) > tbest)) return v;
+            } else {
+                return sp < ST::kCapacity ? (int32_t)s.overflow[(size_t)(sp - ST::kLds) * s.stride] : 0;
+            }
+        }
+        return kDoneNode;
+    } else {
+        return sp ? stack_pop(s, sp) : kDoneNode;
+    }
 }
 
 // One primitive record against the ray; keeps the (t, id)-smallest hit, which is
@@ -264,7 +292,7 @@ __device__ __forceinline__ int32_t node_step2(const SceneDev &sc, int32_t node, 
     }
     if (hl) return cl;
     if (hr) return cr;
-    return sp ? stack_pop(st, sp) : kDoneNode;
+    return stack_next(st, sp, tbest);
 }
 
 __device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
@@ -327,14 +355,19 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
         st.lds[sp * ST::kStride] = (uint32_t)e0;
         st.lds[(sp + 1) * ST::kStride] = (uint32_t)e1;
         st.lds[(sp + 2) * ST::kStride] = (uint32_t)c1;
+        if constexpr (ST::kWithT) {
+            st.lds_t[sp * ST::kStride] = np == 3 ? key[3] : np == 2 ? key[2] : key[1];
+            st.lds_t[(sp + 1) * ST::kStride] = np == 3 ? key[2] : key[1];
+            st.lds_t[(sp + 2) * ST::kStride] = key[1];
+        }
         sp += np;
     } else {
-        if (np == 3) stack_push(st, sp, c3);
-        if (np >= 2) stack_push(st, sp, c2);
-        if (np >= 1) stack_push(st, sp, c1);
+        if (np == 3) stack_push(st, sp, c3, key[3]);
+        if (np >= 2) stack_push(st, sp, c2, key[2]);
+        if (np >= 1) stack_push(st, sp, c1, key[1]);
     }
     if (empty && key[0] == 0xffffffffu) (*empty)++;   // -DPT_COUNT_EMPTY only
-    if (key[0] == 0xffffffffu) return sp ? stack_pop(st, sp) : kDoneNode;
+    if (key[0] == 0xffffffffu) return stack_next(st, sp, tbest);
     return c0;
 }
 
@@ -364,7 +397,7 @@ __device__ __forceinline__ int32_t leaf_step(const SceneDev &sc, int32_t node, f
         if (two) intersect_record(a1, b1, c1, first + k + 1, o, d, tbest, idbest, recbest);
     }
     n_prims += count;
-    return sp ? stack_pop(st, sp) : kDoneNode;
+    return stack_next(st, sp, tbest);
 }
 
 // ---- two-level scenes: mesh objects that share a mesh keep one tree over the mesh's object-space triangles, and the
@@ -1034,10 +1067,24 @@ __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && n
 template <int WIDE, bool MAT, bool INST = false>
 __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 {
+#if PT_STACK_T
+    // measurement build: half as many stack entries in LDS, each with its entry distance (same LDS footprint)
+    constexpr bool kCull = WIDE == 4 && !INST;
+    constexpr int kLdsEntries = kCull ? PT_STACK_T : kStackLds;
+    typedef StackT<kLdsEntries, kBlock, kCull> PathStack;
+    __shared__ uint32_t lds_stack[kLdsEntries * kBlock];
+    __shared__ uint32_t lds_stack_t[kCull ? kLdsEntries * kBlock : 1];
+#else
+    typedef Stack PathStack;
     __shared__ uint32_t lds_stack[kStackLds * kBlock];
+#endif
     __shared__ float lds_save[3 * kBlock];   // node, sp, ray_work parked here during a shade phase
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x, n_threads = gridDim.x * kBlock;
-    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads};
+#if PT_STACK_T
+    const PathStack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads, lds_stack_t + threadIdx.x};
+#else
+    const PathStack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads};
+#endif
     const int lane = threadIdx.x & 63;
     const SceneDev &sc = a.sc;
     __shared__ float4 lds_state[4 * kBlock];   // ls0 .. ls3 of every thread, [slot][thread]
@@ -1354,22 +1401,58 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 
 // order[] = the blocks by falling cost (a counting sort on the clamped cost; ties in no particular order: any
 // permutation renders the same image), and the counters back to zero for the frame that is about to start.
-constexpr int kOrderThreads = 1024, kOrderBins = 2048, kOrderShift = 3;   // a block's 64 first paths cost some thousands of steps: bins of 8
+// One small workgroup - four waves, 2 KB of LDS, 16 registers - so that it fits beside the resident workgroups of other
+// contexts' path kernels: five of those per CU leave three wave slots per SIMD, 32 registers per lane and, after the LDS
+// allocator's rounding, under 4 KB of LDS.  A kernel trace of three dispatches in flight showed the earlier forms (1024
+// threads and 8 KB; 256 threads and 4.1 KB) pending for 6-7 ms on average, up to 22 ms, until a CU had drained, and the
+// context's next frame behind them; this one starts at once (0.11 ms) and the three-in-flight rate is 0.8 % higher.
+constexpr int kOrderThreads = 256, kOrderBins = 512, kOrderShift = 5;    // a block's 64 first paths cost some thousands of steps: bins of 32
 __global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *cost, uint32_t *order, uint32_t n_blocks)
 {
     __shared__ uint32_t bin[kOrderBins];
-    for (int i = threadIdx.x; i < kOrderBins; i += kOrderThreads) bin[i] = 0;
+    __shared__ uint32_t wave_sum[kOrderThreads / 64];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < kOrderBins; i += kOrderThreads) bin[i] = 0;
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) atomicAdd(&bin[min(cost[b] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {                 // first rank of every bin, most expensive bin first
-        uint32_t run = 0;
-        for (int i = kOrderBins - 1; i >= 0; i--) { const uint32_t c = bin[i]; bin[i] = run; run += c; }
+    // four blocks per thread and round, so that four loads are in flight
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4 * kOrderThreads) {
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t b = b0 + j * kOrderThreads + t; c[j] = b < n_blocks ? cost[b] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (b0 + j * kOrderThreads + t < n_blocks) atomicAdd(&bin[min(c[j] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += kOrderThreads) {
-        order[atomicAdd(&bin[min(cost[b] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u)] = b;
-        cost[b] = 0;
+    // first rank of every bin, most expensive bin first: thread t owns the four bins of rank 4t .. 4t+3 from the top
+    {
+        constexpr int kPer = kOrderBins / kOrderThreads;
+        uint32_t c[kPer], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) { c[j] = bin[kOrderBins - 1 - (t * kPer + j)]; sum += c[j]; }
+        uint32_t incl = sum;                                   // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((t & 63u) >= (uint32_t)off) incl += v; }
+        if ((t & 63u) == 63u) wave_sum[t >> 6] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < (t >> 6); w++) run += wave_sum[w];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) { bin[kOrderBins - 1 - (t * kPer + j)] = run; run += c[j]; }
+    }
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4 * kOrderThreads) {
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t b = b0 + j * kOrderThreads + t; c[j] = b < n_blocks ? cost[b] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t b = b0 + j * kOrderThreads + t;
+            if (b < n_blocks) {
+                order[atomicAdd(&bin[min(c[j] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u)] = b;
+                cost[b] = 0;
+            }
+        }
     }
 }
 
