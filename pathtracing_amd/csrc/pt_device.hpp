@@ -624,8 +624,13 @@ __device__ __forceinline__ f3 sky_sample(const SceneDev &sc, f3 dir)
     float x = phi * (float)W - 0.5f, y = theta * (float)H - 0.5f;
     float x0f = pt_floor(x), y0f = pt_floor(y);
     float fx = x - x0f, fy = y - y0f;
-    int x0 = (int)x0f % W; if (x0 < 0) x0 += W;
-    int y0 = (int)y0f % H; if (y0 < 0) y0 += H;
+    int x0, y0;
+    if (((W & (W - 1)) | (H & (H - 1))) == 0) {     // sizes that are powers of two (wave-uniform): the non-negative residue is a mask
+        x0 = (int)x0f & (W - 1); y0 = (int)y0f & (H - 1);
+    } else {
+        x0 = (int)x0f % W; if (x0 < 0) x0 += W;
+        y0 = (int)y0f % H; if (y0 < 0) y0 += H;
+    }
     int x1 = x0 + 1 == W ? 0 : x0 + 1, y1 = y0 + 1 == H ? 0 : y0 + 1;
     float4 c00 = sc.sky[(size_t)y0 * W + x0], c10 = sc.sky[(size_t)y0 * W + x1];
     float4 c01 = sc.sky[(size_t)y1 * W + x0], c11 = sc.sky[(size_t)y1 * W + x1];
@@ -723,9 +728,18 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
         }
     }
     hit_pos = position;
-    result.x += energy.x * emitted.x / fspp;
-    result.y += energy.y * emitted.y / fspp;
-    result.z += energy.z * emitted.z / fspp;
+    if ((__float_as_uint(fspp) & 0x007fffffu) == 0u) {
+        // a power of two (wave-uniform): x / 2^k and x * 2^-k are the same correctly rounded number, and the product
+        // costs one instruction where the division costs eleven
+        const float inv = 1.0f / fspp;
+        result.x += energy.x * emitted.x * inv;
+        result.y += energy.y * emitted.y * inv;
+        result.z += energy.z * emitted.z * inv;
+    } else {
+        result.x += energy.x * emitted.x / fspp;
+        result.y += energy.y * emitted.y / fspp;
+        result.z += energy.z * emitted.z / fspp;
+    }
     if (!hit) {
         energy = pt_make3(0, 0, 0);
         return;
@@ -805,7 +819,14 @@ __device__ __forceinline__ void camera_ray(const RenderArgs &a, int px, int py, 
 // With a block order the item's block is looked up instead: the frame's work counters each hand out a contiguous range
 // of items, and counter s takes the blocks of rank s, s + n, s + 2n, ... (n counters), so that every counter - and with
 // them the frame as a whole - goes from the most expensive blocks to the cheapest: the pixels still in flight when the
-// counters run dry are then cheap ones, which shortens the tail of a persistent dispatch.
+// counters run dry are then cheap ones, which shortens the tail of a persistent dispatch.  The table holds a block as
+// column | row << 16 (order_blocks_kernel), so the lookup needs no division.
+__device__ __forceinline__ bool block_pixel(const RenderArgs &a, uint32_t bx, uint32_t by, uint32_t in, int &x, int &y)
+{
+    x = a.tx0 + (int)bx * 8 + (int)(in & 7u);
+    y = a.ty0 + (int)by * 8 + (int)(in >> 3);
+    return x < a.tx0 + a.tw && y < a.ty0 + a.th;
+}
 __device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, int &x, int &y)
 {
     uint32_t blk = item >> 6, in = item & 63u;
@@ -813,12 +834,23 @@ __device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, i
         const uint32_t shard_blocks = a.shard_items >> 6;
         const uint32_t rank = (blk % shard_blocks) * (uint32_t)a.n_shards + blk / shard_blocks;
         if (rank >= a.n_blocks) { x = y = 0; return false; }
-        blk = a.block_order[rank];
+        const uint32_t packed = a.block_order[rank];
+        return block_pixel(a, packed & 0xffffu, packed >> 16, in, x, y);
     }
-    int bx = (int)(blk % (uint32_t)a.tiles_x), by = (int)(blk / (uint32_t)a.tiles_x);
-    x = a.tx0 + bx * 8 + (int)(in & 7u);
-    y = a.ty0 + by * 8 + (int)(in >> 3);
-    return x < a.tx0 + a.tw && y < a.ty0 + a.th;
+    return block_pixel(a, blk % (uint32_t)a.tiles_x, blk / (uint32_t)a.tiles_x, in, x, y);
+}
+// The same for an item a wave has just claimed from work counter `shard`: `pos` is the item's place in that counter's
+// range, so the counter and the place need not be divided out of the item number again.
+__device__ __forceinline__ bool claimed_pixel(const RenderArgs &a, uint32_t shard, uint32_t pos, int &x, int &y)
+{
+    if (a.block_order) {
+        const uint32_t rank = (pos >> 6) * (uint32_t)a.n_shards + shard;
+        if (rank >= a.n_blocks) { x = y = 0; return false; }
+        const uint32_t packed = a.block_order[rank];
+        return block_pixel(a, packed & 0xffffu, packed >> 16, pos & 63u, x, y);
+    }
+    const uint32_t blk = shard * (a.shard_items >> 6) + (pos >> 6);
+    return block_pixel(a, blk % (uint32_t)a.tiles_x, blk / (uint32_t)a.tiles_x, pos & 63u, x, y);
 }
 
 // What a pixel's first path cost (node visits + primitive tests, or 16 per ray where those are not at hand) goes to its
@@ -1136,6 +1168,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             }
             const bool was_done = node == kDoneNode, was_idle = node == kIdleNode;
             bool new_ray = false, finished = false, no_more = false;
+            int cam_x = -1, cam_y = 0;             // >= 0: the new ray is this pixel's camera ray (next sample of a pixel, or a new pixel)
             bool cached = false;                   // new_ray whose hit is already known (the pixel's primary hit)
             float cached_t = PT_INF; int32_t cached_id = -1; uint32_t cached_rec = 0;
             int4 cnt = make_int4(0, 0, 0, 0);
@@ -1203,7 +1236,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         if (sample < a.spp) {                          // next sample of the same pixel, SH:839
                             bounce = 0;
                             energy = pt_make3(1, 1, 1);
-                            camera_ray<MAT>(a, pix_x, pix_y, o, d);
+                            cam_x = pix_x; cam_y = pix_y;              // its camera ray is made below, together with the new pixels'
                             cnt.w++;
                             if (a.reuse_primary) {
                                 // SH:842 has no jitter: every sample of a pixel starts with the same camera ray, so
@@ -1249,7 +1282,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             const bool need = was_idle || finished;
             unsigned long long m = __ballot(need);
             if (m) {
-                uint32_t item = 0; bool got = false;
+                uint32_t item_pos = 0, item_shard = 0; bool got = false;     // the claimed item: its counter and its place there
                 int tries = 0;
                 while (m && !frame_drained) {
                     const int leader = __ffsll((long long)m) - 1;
@@ -1258,8 +1291,8 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     base = __shfl(base, leader);
                     const uint32_t sbeg = (uint32_t)shard * a.shard_items;
                     const uint32_t send = min(sbeg + a.shard_items, a.total_items);
-                    const uint32_t mine = sbeg + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (need && !got && mine < send && base < a.shard_items) { item = mine; got = true; }
+                    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (need && !got && sbeg + pos < send && base < a.shard_items) { item_pos = pos; item_shard = (uint32_t)shard; got = true; }
                     m = __ballot(need && !got);
                     if (m) {
                         shard = shard + 1 == a.n_shards ? 0 : shard + 1;
@@ -1271,11 +1304,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         no_more = true;
                     } else {
                         int x, y;
-                        if (item_pixel(a, item, x, y) && !(MAT && a.skip_t && !(a.skip_t[(size_t)y * a.W + x] < PT_INF))) {
+                        if (claimed_pixel(a, item_shard, item_pos, x, y) && !(MAT && a.skip_t && !(a.skip_t[(size_t)y * a.W + x] < PT_INF))) {
                             *ls0 = make_float4(1.0f, 1.0f, 1.0f, a.seed);
                             *ls1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                             *ls2 = make_int4(x | (y << 16), kFirstSample, 0, -1);   // first sample, no work yet, bounce 0, no primary hit yet
-                            camera_ray<MAT>(a, x, y, o, d);
+                            cam_x = x; cam_y = y;
                             cnt.w++;
                             new_ray = true;
                         }
@@ -1290,6 +1323,8 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             }
             if (no_more) node = kDeadNode;
             else if (finished && !new_ray) node = kIdleNode;   // pixel done, its replacement lay outside the tile
+            // one camera ray for both kinds of regeneration: the wave runs this code once instead of twice
+            if (new_ray && cam_x >= 0) camera_ray<MAT>(a, cam_x, cam_y, o, d);
             if (new_ray) {
                 tbest = PT_INF; idbest = -1; recbest = 0;
                 intersect_ground_plane(o, d, tbest, idbest);
@@ -1399,7 +1434,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     path_sched_body<WIDE, true>(a);
 }
 
-// order[] = the blocks by falling cost (a counting sort on the clamped cost; ties in no particular order: any
+// order[] = the blocks (column | row << 16) by falling cost (a counting sort on the clamped cost; ties in no particular order: any
 // permutation renders the same image), and the counters back to zero for the frame that is about to start.
 // One small workgroup - four waves, 2 KB of LDS, 16 registers - so that it fits beside the resident workgroups of other
 // contexts' path kernels: five of those per CU leave three wave slots per SIMD, 32 registers per lane and, after the LDS
@@ -1407,7 +1442,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 // threads and 8 KB; 256 threads and 4.1 KB) pending for 6-7 ms on average, up to 22 ms, until a CU had drained, and the
 // context's next frame behind them; this one starts at once (0.11 ms) and the three-in-flight rate is 0.8 % higher.
 constexpr int kOrderThreads = 256, kOrderBins = 512, kOrderShift = 5;    // a block's 64 first paths cost some thousands of steps: bins of 32
-__global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *cost, uint32_t *order, uint32_t n_blocks)
+__global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *cost, uint32_t *order, uint32_t n_blocks, uint32_t tiles_x)
 {
     __shared__ uint32_t bin[kOrderBins];
     __shared__ uint32_t wave_sum[kOrderThreads / 64];
@@ -1449,7 +1484,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *c
         for (int j = 0; j < 4; j++) {
             const uint32_t b = b0 + j * kOrderThreads + t;
             if (b < n_blocks) {
-                order[atomicAdd(&bin[min(c[j] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u)] = b;
+                order[atomicAdd(&bin[min(c[j] >> kOrderShift, (uint32_t)kOrderBins - 1u)], 1u)] = (b % tiles_x) | ((b / tiles_x) << 16);
                 cost[b] = 0;
             }
         }

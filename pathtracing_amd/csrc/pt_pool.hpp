@@ -337,7 +337,7 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
             const bool need = was_idle || finished;
             unsigned long long m = __ballot(need);
             if (m) {
-                uint32_t item = 0; bool got = false;
+                uint32_t item_pos = 0, item_shard = 0; bool got = false;     // the claimed item: its counter and its place there
                 int tries = 0;
                 while (m && !frame_drained) {
                     const int leader = __ffsll((long long)m) - 1;
@@ -346,8 +346,8 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
                     base = __shfl(base, leader);
                     const uint32_t sbeg = (uint32_t)shard * a.shard_items;
                     const uint32_t send = min(sbeg + a.shard_items, a.total_items);
-                    const uint32_t mine = sbeg + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (need && !got && mine < send && base < a.shard_items) { item = mine; got = true; }
+                    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (need && !got && sbeg + pos < send && base < a.shard_items) { item_pos = pos; item_shard = (uint32_t)shard; got = true; }
                     m = __ballot(need && !got);
                     if (m) {
                         shard = shard + 1 == a.n_shards ? 0 : shard + 1;
@@ -359,7 +359,7 @@ __device__ __forceinline__ void path_pool_body(const RenderArgs &a)
                         no_more = true;
                     } else {
                         int x, y;
-                        if (item_pixel(a, item, x, y) && !(MAT && a.skip_t && !(a.skip_t[(size_t)y * a.W + x] < PT_INF))) {
+                        if (claimed_pixel(a, item_shard, item_pos, x, y) && !(MAT && a.skip_t && !(a.skip_t[(size_t)y * a.W + x] < PT_INF))) {
                             g0[gslot] = make_float4(1.0f, 1.0f, 1.0f, a.seed);
                             g1[gslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                             g2[gslot] = make_int4(x | (y << 16), 0, 0, -1);   // sample 0, bounce 0, no primary hit yet

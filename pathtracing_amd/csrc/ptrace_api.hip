@@ -1381,7 +1381,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         int done() const
         {
             if (!want) return PT_OK;
-            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(kOrderThreads), 0, ctx->stream, ctx->d_block_cost, ctx->d_block_order, a.n_blocks);
+            hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(kOrderThreads), 0, ctx->stream, ctx->d_block_cost, ctx->d_block_order, a.n_blocks, (uint32_t)a.tiles_x);
             if (hipGetLastError() != hipSuccess) return PT_ERR_HIP;
             std::memcpy(ctx->order_key, key, sizeof ctx->order_key);
             ctx->order_ready = true;
