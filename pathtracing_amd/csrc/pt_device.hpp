@@ -552,8 +552,12 @@ __device__ __forceinline__ void intersect_far_spheres(const SceneDev &sc, f3 o, 
 {
     if (sc.n_spheres == 0) return;
     const float dx = o.x - sc.centre[0], dy = o.y - sc.centre[1], dz = o.z - sc.centre[2];
-    const float dist = sqrtf(dx * dx + dy * dy + dz * dz) + sc.half_diag;
-    if (!(dist > sc.far_reach)) return;
+    // |o - centre| + half_diag > far_reach, asked of the squares: every new ray of every shade phase comes through here,
+    // and the root is only worth taking for the few that pass (where exactly the line lies does not matter: the tree's
+    // boxes cover rays from anywhere near it as well)
+    const float d2 = dx * dx + dy * dy + dz * dz, lim = sc.far_reach - sc.half_diag;
+    if (!(lim < 0.0f || d2 > lim * lim)) return;
+    const float dist = sqrtf(d2) + sc.half_diag;
     // the spheres' bounds, widened by what the spheres look wider by from there, against the ray (conservative slab test)
     const float m = 7.5e-4f * dist + 1e-3f * sc.half_diag;
     float tn = 0.0f, tf = PT_INF;
