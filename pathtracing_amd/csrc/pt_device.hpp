@@ -116,7 +116,7 @@ struct RenderArgs {
     int32_t copy_all;             // renderMode 7 / 8, first dispatch of a cycle: the pixel also goes to Result1 and Result (SH:944-947)
     // expensive blocks first (both path kernels)
     const uint32_t *block_order;  // NULL, or the 8x8 pixel blocks of the tile rectangle by falling cost of the previous frame
-    uint32_t *block_cost;         // NULL, or one counter per block: path length of every pixel's first sample, for the next frame's order
+    uint32_t *block_cost;         // NULL, or one counter per block: the most work a first sample of its pixels took, for the next frame's order
     uint32_t n_blocks;            // blocks in the tile rectangle
     // path_pool_kernel (pt_pool.hpp)
     float4 *pool_state;           // 3 x float4 per slot of the grid: what only Shade() touches
@@ -858,12 +858,14 @@ __device__ __forceinline__ bool claimed_pixel(const RenderArgs &a, uint32_t shar
 }
 
 // What a pixel's first path cost (node visits + primitive tests, or 16 per ray where those are not at hand) goes to its
-// block's cost counter.
+// block's cost counter, which keeps the largest.
 constexpr int kFirstSample = 1 << 19;
 __device__ __forceinline__ void note_cost(const RenderArgs &a, int pix_x, int pix_y, int work)
 {
+    // the block's most expensive pixel, not the sum of its pixels: what has to start early is whatever holds a long pixel
+    // (measured against the sum: +1 % one dispatch at a time and three in flight)
     if (a.block_cost)
-        atomicAdd(a.block_cost + (uint32_t)((pix_y - a.ty0) >> 3) * (uint32_t)a.tiles_x + (uint32_t)((pix_x - a.tx0) >> 3), (uint32_t)work);
+        atomicMax(a.block_cost + (uint32_t)((pix_y - a.ty0) >> 3) * (uint32_t)a.tiles_x + (uint32_t)((pix_x - a.tx0) >> 3), (uint32_t)work);
 }
 
 // dot(_Pixel, float2(12.9898, 78.233)) with _Pixel = id.xy * 2 (SH:831, SH:52)
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 // allocator's rounding, under 4 KB of LDS.  A kernel trace of three dispatches in flight showed the earlier forms (1024
 // threads and 8 KB; 256 threads and 4.1 KB) pending for 6-7 ms on average, up to 22 ms, until a CU had drained, and the
 // context's next frame behind them; this one starts at once (0.11 ms) and the three-in-flight rate is 0.8 % higher.
-constexpr int kOrderThreads = 256, kOrderBins = 512, kOrderShift = 5;    // a block's 64 first paths cost some thousands of steps: bins of 32
+constexpr int kOrderThreads = 256, kOrderBins = 512, kOrderShift = 0;    // a pixel's first path costs tens to some hundreds of steps: a bin per step
 __global__ __launch_bounds__(kOrderThreads) void order_blocks_kernel(uint32_t *cost, uint32_t *order, uint32_t n_blocks, uint32_t tiles_x)
 {
     __shared__ uint32_t bin[kOrderBins];
