@@ -161,7 +161,7 @@ struct StackT {
     uint32_t *lds;        // entry 0 of this lane's stack; entry e lies LDS_STRIDE words further per entry
     uint32_t *overflow;   // entry LDS_ENTRIES of this lane's stack in the global buffer
     uint32_t stride;      // words between consecutive overflow entries (stacks in the grid)
-    uint32_t *lds_t;      // WITH_T: the entry distances' bits
+    uint32_t *lds_t = nullptr;   // WITH_T: the entry distances' bits
     static constexpr int kLds = LDS_ENTRIES, kStride = LDS_STRIDE;
     static constexpr bool kWithT = WITH_T;
     static constexpr int kCapacity = WITH_T ? LDS_ENTRIES + kStackOverflow : kStackLds + kStackOverflow;
