@@ -70,6 +70,7 @@ struct RenderArgs {
     int32_t W, H;
     int32_t tx0, ty0, tw, th;     // tile rectangle
     int32_t tiles_x;              // 8x8 pixel blocks per row of the tile rectangle
+    uint32_t tiles_x_magic;       // 0, or floor(2^32 / tiles_x) + 1: then block / tiles_x = umulhi(block, magic) for every block of the rectangle
     uint32_t total_items;         // tiles_x * tiles_y * 64
     float4 *result;
     float4 *converged;
@@ -831,6 +832,16 @@ __device__ __forceinline__ bool block_pixel(const RenderArgs &a, uint32_t bx, ui
     y = a.ty0 + (int)by * 8 + (int)(in >> 3);
     return x < a.tx0 + a.tw && y < a.ty0 + a.th;
 }
+// Row-major block number -> column and row.  The host sets the multiplier when it is exact for every block of the
+// rectangle (blocks * tiles_x < 2^32); a 32-bit division costs some thirty instructions, and at one sample per pixel
+// every shade phase claims pixels.
+__device__ __forceinline__ bool numbered_pixel(const RenderArgs &a, uint32_t blk, uint32_t in, int &x, int &y)
+{
+    uint32_t bx, by;
+    if (a.tiles_x_magic) { by = __umulhi(blk, a.tiles_x_magic); bx = blk - by * (uint32_t)a.tiles_x; }
+    else { by = blk / (uint32_t)a.tiles_x; bx = blk % (uint32_t)a.tiles_x; }
+    return block_pixel(a, bx, by, in, x, y);
+}
 __device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, int &x, int &y)
 {
     uint32_t blk = item >> 6, in = item & 63u;
@@ -841,7 +852,7 @@ __device__ __forceinline__ bool item_pixel(const RenderArgs &a, uint32_t item, i
         const uint32_t packed = a.block_order[rank];
         return block_pixel(a, packed & 0xffffu, packed >> 16, in, x, y);
     }
-    return block_pixel(a, blk % (uint32_t)a.tiles_x, blk / (uint32_t)a.tiles_x, in, x, y);
+    return numbered_pixel(a, blk, in, x, y);
 }
 // The same for an item a wave has just claimed from work counter `shard`: `pos` is the item's place in that counter's
 // range, so the counter and the place need not be divided out of the item number again.
@@ -853,8 +864,7 @@ __device__ __forceinline__ bool claimed_pixel(const RenderArgs &a, uint32_t shar
         const uint32_t packed = a.block_order[rank];
         return block_pixel(a, packed & 0xffffu, packed >> 16, pos & 63u, x, y);
     }
-    const uint32_t blk = shard * (a.shard_items >> 6) + (pos >> 6);
-    return block_pixel(a, blk % (uint32_t)a.tiles_x, blk / (uint32_t)a.tiles_x, pos & 63u, x, y);
+    return numbered_pixel(a, shard * (a.shard_items >> 6) + (pos >> 6), pos & 63u, x, y);
 }
 
 // What a pixel's first path cost (node visits + primitive tests, or 16 per ray where those are not at hand) goes to its
@@ -1208,6 +1218,9 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                     float t_primary = s1.w;
                     Rng rs = {s0.w, pixel_dot(pix_x, pix_y)};
                     f3 hit_pos;
+                    // plain path tracing, also inside a stripe (renderMode 1, 5, 6, 10, 11, 12): the pixel is (result, distance of the primary hit)
+                    const bool alpha_early = !(a.render_mode == 0 || a.render_mode == 2 ||
+                                               (MAT && (a.render_mode == 3 || a.render_mode == 4 || a.render_mode == 7 || a.render_mode == 8)));
                     bool from_history = false;
                     if (MAT && a.render_mode == 10 && bounce == 0 && sample == 0) {
                         // SH:1048-1057: a primary hit the history already shows is copied from there and no path is traced.
@@ -1230,6 +1243,13 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         primary_id = idbest;
                         primary_rec = recbest;
                         t_primary = tbest;
+                        // Where the pixel's final write needs nothing of the primary hit but its distance from the camera
+                        // (SH:860, SH:935), that distance is taken here, when the LAST sample's primary hit comes back - hit_pos
+                        // is the very bestHit.position the write would rebuild from a second camera ray - and kept in place
+                        // of t, which no later sample will ask for.  At one sample per pixel this spares every shade phase a
+                        // camera ray.
+                        if (alpha_early && sample + 1 >= a.spp)
+                            t_primary = pt_length3(pt_sub3(hit_pos, pt_make3(a.c2w[12], a.c2w[13], a.c2w[14])));
                         path_done = !(tbest < PT_INF) || a.maxb <= 1;   // primary miss: see the note above
                     } else {
                         path_done = !(energy.x != 0.0f || energy.y != 0.0f || energy.z != 0.0f) || bounce + 1 >= a.maxb;
@@ -1253,16 +1273,22 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                             // SH:860, SH:935: hitPos of the (last) sample's primary ray, (0,0,0) after a miss, and
                             // its distance from the camera; every sample of a pixel has the same primary ray
                             size_t p = (size_t)pix_y * a.W + pix_x;
-                            f3 co, cd;
-                            camera_ray<MAT>(a, pix_x, pix_y, co, cd);
-                            const bool sky = !(t_primary < PT_INF);
-                            const f3 hit_pos0 = sky ? pt_make3(0, 0, 0) : pt_along3(co, t_primary, cd);
                             const bool full_reproj = MAT && (a.render_mode == 7 || a.render_mode == 8);
-                            const f3 alpha_from = full_reproj ? pt_make3(a.alpha_origin[0], a.alpha_origin[1], a.alpha_origin[2]) : co;
-                            const float alpha_dist = pt_length3(pt_sub3(hit_pos0, alpha_from));
-                            float4 fresh = make_float4(result.x, result.y, result.z, alpha_dist);
-                            if (MAT && (a.render_mode == 3 || a.render_mode == 4)) fresh = reproject_pixel_ext(a, result, hit_pos0, sky, alpha_dist);
-                            else if (a.render_mode == 0 || a.render_mode == 2) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist, pix_y);
+                            float4 fresh;
+                            if (alpha_early) {
+                                // the slot has held the distance itself since the last sample's primary hit came back (above)
+                                fresh = make_float4(result.x, result.y, result.z, t_primary);
+                            } else {
+                                f3 co, cd;
+                                camera_ray<MAT>(a, pix_x, pix_y, co, cd);
+                                const bool sky = !(t_primary < PT_INF);
+                                const f3 hit_pos0 = sky ? pt_make3(0, 0, 0) : pt_along3(co, t_primary, cd);
+                                const f3 alpha_from = full_reproj ? pt_make3(a.alpha_origin[0], a.alpha_origin[1], a.alpha_origin[2]) : co;
+                                const float alpha_dist = pt_length3(pt_sub3(hit_pos0, alpha_from));
+                                fresh = make_float4(result.x, result.y, result.z, alpha_dist);
+                                if (MAT && (a.render_mode == 3 || a.render_mode == 4)) fresh = reproject_pixel_ext(a, result, hit_pos0, sky, alpha_dist);
+                                else if (a.render_mode == 0 || a.render_mode == 2) fresh = reproject_pixel(a, result, hit_pos0, sky, alpha_dist, pix_y);
+                            }
                             if (a.render_mode == 0) { a.result2[p] = fresh; a.seed_out[p] = rs.seed; }
                             else if (full_reproj) {                    // SH:938-948
                                 a.result2[p] = fresh;

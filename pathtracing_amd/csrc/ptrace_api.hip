@@ -1328,15 +1328,25 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
     return PT_OK;
 }
 
+// The rectangle's 8x8 pixel blocks: blocks per row, work items, and the multiplier that stands in for the division by the
+// blocks per row (pt_device.hpp, numbered_pixel): with m = floor(2^32 / d) + 1, floor(n m / 2^32) = floor(n / d) whenever n d < 2^32.
+static void set_tiles(RenderArgs &a, int tw, int th)
+{
+    a.tiles_x = (tw + 7) / 8;
+    const int tiles_y = (th + 7) / 8;
+    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    // the counters hand out up to one block per counter beyond the rectangle's last: kWorkShards more than it holds
+    const uint64_t blocks = (uint64_t)a.tiles_x * (uint64_t)tiles_y + (uint64_t)kWorkShards;
+    a.tiles_x_magic = a.tiles_x > 1 && blocks * (uint64_t)a.tiles_x < (1ull << 32) ? (uint32_t)((1ull << 32) / (uint64_t)a.tiles_x + 1ull) : 0u;
+}
+
 // Path-trace the rectangle (x0, y0, tw, th) with the arguments in `a` (everything but the tile fields filled in).
 static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, int th)
 {
     if (tw <= 0 || th <= 0) return PT_OK;
     int rc;
     a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th;
-    a.tiles_x = (tw + 7) / 8;
-    const int tiles_y = (th + 7) / 8;
-    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    set_tiles(a, tw, th);
     const bool instanced = ctx->n_inst > 0;        // two-level scene: path_sched_inst_kernel, whatever the backend option says
     const bool extended = instanced || ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
     // the wavefront stages pack a path's bounce count into 8 bits (pt_wavefront.hpp): longer paths go to the scheduled kernel
@@ -1443,9 +1453,7 @@ static int launch_primary(pt_context *ctx, RenderArgs &a, int what, int x0, int 
     if (tw <= 0 || th <= 0) return PT_OK;
     int rc;
     a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th;
-    a.tiles_x = (tw + 7) / 8;
-    const int tiles_y = (th + 7) / 8;
-    a.total_items = (uint32_t)a.tiles_x * (uint32_t)tiles_y * 64u;
+    set_tiles(a, tw, th);
     const int grid = (int)std::min<int64_t>(((int64_t)a.total_items + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8 * 4);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
@@ -1538,7 +1546,7 @@ static int render_frame(pt_context *ctx, const PtFrameParams *p)
     std::memcpy(a.ip, p->camera_inverse_projection, sizeof a.ip);
     a.seed = p->seed; a.spp = p->samples_per_pixel; a.maxb = p->max_bounces; a.depth = p->depth == 1 ? 1 : 0;
     a.W = ctx->W; a.H = ctx->H;
-    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th; a.tiles_x = 0; a.total_items = 0;
+    a.tx0 = x0; a.ty0 = y0; a.tw = tw; a.th = th; a.tiles_x = 0; a.tiles_x_magic = 0; a.total_items = 0;
     a.result = ctx->result; a.converged = ctx->conv; a.hit_ids = ctx->ids;
     a.accumulate = p->accumulate; a.sample_index = p->sample_index;
     a.work_counter = ctx->d_work; a.stats = ctx->d_stats;
