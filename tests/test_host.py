@@ -303,3 +303,26 @@ def test_radiance_hdr_sky_loader(tmp_path):
     for name, why in (("short.hdr", "ends early"), ("magic.hdr", "not a Radiance"), ("xyze.hdr", "32-bit_rle_rgbe"), ("absent.hdr", "cannot open")):
         with pytest.raises(ValueError, match=why):
             pa.load_hdr(tmp_path / name)
+
+
+def test_block_row_multiplier_is_exact():
+    """pt_render numbers a rectangle's 8x8 pixel blocks row by row and the kernels turn a block number n back into
+    (n % tiles_x, n / tiles_x).  Where blocks * tiles_x < 2^32 the host hands them m = floor(2^32 / tiles_x) + 1 and they take
+    n / tiles_x = (n * m) >> 32 (csrc/ptrace_api.hip set_tiles, csrc/pt_device.hpp numbered_pixel); this restates the rule and
+    checks it at every multiple of tiles_x, one below and one above, up to the largest block number the rule admits."""
+    rng = np.random.default_rng(7)
+    sizes = [(2, 1), (3, 5), (240, 135), (258, 276), (480, 270), (1000, 1000), (1625, 1625), (65535, 1)]
+    sizes += [(int(rng.integers(2, 1500)), int(rng.integers(1, 1500))) for _ in range(200)]
+    checked = 0
+    for tiles_x, tiles_y in sizes:
+        blocks = tiles_x * tiles_y + 64                      # kWorkShards more than the rectangle holds
+        if blocks * tiles_x >= 1 << 32:
+            continue                                         # the host sets no multiplier: the kernels divide
+        m = (1 << 32) // tiles_x + 1
+        assert m < 1 << 32
+        rows = np.arange(0, blocks // tiles_x + 1, dtype=np.uint64)
+        for n in (rows * tiles_x, rows * tiles_x + (tiles_x - 1), np.array([blocks - 1], np.uint64)):
+            n = n[n < blocks]
+            assert ((n * np.uint64(m)) >> np.uint64(32) == n // np.uint64(tiles_x)).all(), (tiles_x, tiles_y)
+        checked += 1
+    assert checked > 100
