@@ -1359,8 +1359,10 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         // samples: claims are rare, and one counter keeps all waves on neighbouring pixels (cache-friendly).
         const uint32_t blocks = a.total_items / 64u;     // 8x8 pixel blocks
         // Measured at 1080p: 1 spp 0.74 -> 0.42 ms (small scene) and 1.39 -> 1.02 ms (262 k triangles) going from 1 to 16
-        // counters, slower again beyond 32; at 16 spp 1 .. 16 counters are within noise of each other.
-        int shards = a.depth ? 16 : std::max(4, 16 / std::max(1, a.spp));
+        // counters, slower again beyond 32.  Eight - a wave starts on counter blockIdx % 8, so the workgroups of one XCD share
+        // one - is the best count for one-sample frames (4 and 16: 2 - 5 % slower) and for cheap scenes at 16 spp (the
+        // 70 k-triangle scene: 9 900 -> 11 000 Mrays/s against four counters); the 262 k-triangle scene does not care.
+        int shards = a.depth ? 16 : 8;
         if (const char *env = std::getenv("PTRACE_SHARDS")) shards = std::atoi(env);
         a.n_shards = std::max(1, std::min(kWorkShards, shards));
         a.shard_items = ((blocks + a.n_shards - 1) / a.n_shards) * 64u;
