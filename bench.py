@@ -17,6 +17,8 @@ kernels (counted on the device) per second of wall time, summed over ranks.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -134,13 +136,16 @@ def valu_view(solo, launches, kernel_ms):
 
 def measured_traffic(args):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes, when they were
-    taken on this workload; None otherwise (bench.py cannot run the profiler on itself)."""
+    taken on this workload, and the file they come from; (None, None) otherwise (bench.py cannot run the profiler on
+    itself: this figure is NOT measured by the run that prints it)."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))      # the most recent one
     if not found or (args.scene, args.width, args.height, args.spp, args.bounces) != ("hall260k", 1920, 1080, 16, 8):
-        return None
+        return None, None
     t = json.load(open(found[-1]))
-    return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
+    src = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; kernel %s, %s), not this run" % (
+        os.path.basename(found[-1]), t.get("kernel", "?"), t.get("workload", "?"))
+    return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0, src
 
 
 def limiter_view(kernel):
@@ -152,7 +157,10 @@ def limiter_view(kernel):
     if not found:
         return None
     t = json.load(open(found[-1]))
-    return t.get(kernel, t.get("path_sched_kernel<4>"))
+    view = dict(t.get(kernel, t.get("path_sched_kernel<4>")))
+    view["source"] = "committed file profiles/%s (%s), kernel %s; not this run" % (
+        os.path.basename(found[-1]), t.get("source", "rocprofv3 --pmc passes"), kernel if kernel in t else "path_sched_kernel<4>")
+    return view
 
 
 def gather_ceiling():
@@ -160,7 +168,38 @@ def gather_ceiling():
     as four 16-byte loads, table resident in L2 / Infinity Cache (tools/ubench/gather_rate, profiles/r*_gather_rate.json)."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gather_rate.json")))
-    return json.load(open(found[-1])) if found else None
+    if not found:
+        return None
+    c = json.load(open(found[-1]))
+    c["source"] = "committed file profiles/%s (tools/ubench/gather_rate on an MI355X), not this run" % os.path.basename(found[-1])
+    return c
+
+
+def free_port():
+    """A TCP port nobody listens on right now: bound, read and closed again."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`bench.py --gpus N` with N > 1 and no launcher's environment: start the N ranks here, one process per GPU, exactly as
+    the documented command line does (python -m torch.distributed.run ... bench.py --gpus N ...), relay rank 0's JSON line
+    and leave with the job's exit code.  Runs before anything in this process touches the GPU: the ranks are children,
+    never a replacement of a process that has initialised HIP.  A request for N GPUs therefore yields an N-rank line or a
+    non-zero exit, never a one-rank line."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE; starting the ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    job = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in job.stdout.splitlines() if ln.startswith("{")]
+    for ln in job.stdout.splitlines():
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr, flush=True)
+    if job.returncode == 0 and len(lines) == 1 and json.loads(lines[0]).get("n_gpus") != args.gpus:
+        raise SystemExit("bench.py: the job reported %s GPUs for --gpus %d" % (json.loads(lines[0]).get("n_gpus"), args.gpus))
+    raise SystemExit(job.returncode if job.returncode else (0 if len(lines) == 1 else 1))
 
 
 def setup_dist(args):
@@ -169,8 +208,9 @@ def setup_dist(args):
     if "PTRACE_BENCH_DEVICE" in os.environ:        # rehearsals of the N > 1 path on a box with fewer GPUs than ranks
         local_rank = int(os.environ["PTRACE_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report "
+                         f"one as the other")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
@@ -203,14 +243,30 @@ def make_collective(dist):
 
 
 def rank_table(torch, dist, collective, world, rank, local_rank, rays, dt):
-    """[device ordinal, Mrays/s] of every rank, so that the line shows N ranks took part."""
+    """Device ordinal, device name and Mrays/s of every rank, so that the line shows which N GPUs took part."""
+    name = torch.cuda.get_device_name(local_rank)
     mine = torch.tensor([float(local_rank), rays / dt / 1e6], dtype=torch.float64, device="cuda")
     if dist is None:
-        return [{"rank": 0, "device": local_rank, "mrays_per_s": float(mine[1])}]
+        return [{"rank": 0, "device": local_rank, "device_name": name, "mrays_per_s": float(mine[1])}]
     allr = torch.zeros((world, 2), dtype=torch.float64, device="cuda")
     allr[rank] = mine
     collective(dist.all_reduce, allr, op=dist.ReduceOp.SUM)
-    return [{"rank": r, "device": int(allr[r, 0]), "mrays_per_s": float(allr[r, 1])} for r in range(world)]
+    names = torch.zeros((world, 64), dtype=torch.int32, device="cuda")       # the names, as character codes, summed into place
+    code = list(name.encode("ascii", "replace"))[:64]
+    names[rank, :len(code)] = torch.tensor(code, dtype=torch.int32, device="cuda")
+    collective(dist.all_reduce, names, op=dist.ReduceOp.SUM)
+    return [{"rank": r, "device": int(allr[r, 0]), "device_name": bytes(int(c) for c in names[r].tolist() if c).decode("ascii", "replace"),
+             "mrays_per_s": float(allr[r, 1])} for r in range(world)]
+
+
+def group_view(dist):
+    """What carried the collectives: {"world_size", "backend", "rccl_world_size"} - the last one is the size of the RCCL
+    communicator when the backend is RCCL ("nccl" in torch), None on the host-memory rehearsal backend or without a group."""
+    if dist is None:
+        return {"world_size": 1, "collective_backend": None, "rccl_world_size": None}
+    backend = dist.get_backend()
+    return {"world_size": dist.get_world_size(), "collective_backend": backend,
+            "rccl_world_size": dist.get_world_size() if backend == "nccl" else None}
 
 
 def relative_rmse(a, b):
@@ -220,6 +276,7 @@ def relative_rmse(a, b):
 
 def main():
     args = parse()
+    self_launch(args)               # N > 1 without a launcher: the ranks are started here, before any GPU call
     rank, local_rank, world, dist = setup_dist(args)
     import torch
     import pathtracing_amd as pa
@@ -363,6 +420,7 @@ def main():
         pipe_achieved = pipe_bytes / dt / 1e9
         single = r_rank / solo_launches / (kernel_ms * 1e-3) / 1e6
         ceiling = gather_ceiling()
+        traffic, traffic_source = measured_traffic(args)
         lane_loads = (solo["nodes_visited"] * 4 + solo["prims_tested"] * 3) / solo_launches      # 16-byte loads per lane
         out = {
             "metric": "Mrays/s (all bounces)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
@@ -378,10 +436,10 @@ def main():
                        if world > 1 else "single GPU",
                        "rays_per_step": rays / n_timed / world, "paths_per_step": paths / n_timed / world,
                        "frames_in_image": frames_total, "dispatches_in_flight": n_ctx},
-            "ranks": ranks, "world_size": dist.get_world_size() if dist is not None else 1,
+            "ranks": ranks, **group_view(dist),
             "rmse_vs_one_rank": rmse,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "kernel_ms": kernel_ms, "launches_timed": solo_launches,
                          "pipelined": {"launches_in_flight": n_ctx, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBS,
                                        "effective_ms_per_launch": dt / launches * 1e3},
@@ -400,7 +458,7 @@ def main():
                              "frac_of_l1_gather_ceiling": lane_loads / (kernel_ms * 1e-3) / 1e9 / ceiling["lane_loads_g_per_s"],
                              "ceiling_tb_s": ceiling["lane_loads_g_per_s"] * 16e-3,
                              "guide_rows_from_l2_tb_s": [16.8, 18.8], "guide_rows_from_infinity_cache_tb_s": 8.6,
-                             "note": ceiling["note"]},
+                             "note": ceiling["note"], "source": ceiling["source"]},
                          "limiter": limiter_view(kernel),
                          # the other roofline the kernel could sit under: counted arithmetic against the fp32 vector peak
                          "valu": valu_view(solo, solo_launches, kernel_ms)},
@@ -429,9 +487,14 @@ def main():
             out["value_distinct_rays"] = out["reuse_primary_hit"]["value"]
         if not args.no_reproj and world == 1:
             out["reproj_1080p"] = reproj_frame_time(pa, torch, scene, sky)
+        if not args.no_stereo and world == 1:
+            # the headline workload with the eye advancing 0.02 units per step: every dispatch hands its blocks out by the
+            # costs the PREVIOUS camera position measured
+            out["value_moving_camera"] = moving_camera_rate(pa, tr, scene, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, args)
             out["cpu_baseline_c1"] = cpu_baseline_c1(args)
+            out["c1_gpu"] = c1_gpu(pa, torch)
         print(json.dumps(out), flush=True)
     for t in trs:
         t.close()
@@ -446,7 +509,8 @@ def eye_split_job(args, pa, torch, dist, collective, rank, local_rank, world):
     eyes run on its GPU side by side, one context and stream each.  metric: ms per stereo frame (max over ranks)."""
     W, H = (args.width, args.height) if (args.width, args.height) != (1920, 1080) else (2064, 2208)
     scene = pa.Scene("xr"); sky = pa.procedural_sky(2048, 1024)
-    eyes = [0, 1] if world == 1 else [rank % 2]
+    from pathtracing_amd import distributed as D
+    eyes = [-1, 1] if world == 1 else [D.eye_for_rank(rank, world)]      # -1: left eye, +1: right eye
     sep = 0.022                                                   # TestScene.unity:870
     trs = []
     for e in eyes:
@@ -459,7 +523,7 @@ def eye_split_job(args, pa, torch, dist, collective, rank, local_rank, world):
 
     def frame(k):
         for e, t in zip(eyes, trs):
-            off = np.array([(-0.5 + e) * sep, 0, 0], np.float32)
+            off = np.array([0.5 * e * sep, 0, 0], np.float32)
             t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=4, accumulate=pa.PT_ACCUM_MEAN,
                                     sample_index=min(k, 10), eye=scene.eye + off, target=scene.target + off, fov=90.0))
 
@@ -498,7 +562,7 @@ def eye_split_job(args, pa, torch, dist, collective, rank, local_rank, world):
                                        f"eye r mod 2 of stereo pair r div 2 on rank r ({pairs} pair(s)); no collective in the frame"),
                        "stereo_pairs": pairs},
             "mrays_per_s": float(r_all.item()) / float(t_all.item()) / 1e6, "ranks": ranks,
-            "world_size": dist.get_world_size() if dist is not None else 1, "eye_image_means_rank0": means}), flush=True)
+            **group_view(dist), "eye_image_means_rank0": means}), flush=True)
     for t in trs:
         t.close()
     if dist is not None:
@@ -569,11 +633,52 @@ def row_split_job(args, pa, torch, D, dist, collective, rank, local_rank, world)
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t_all.item()) / args.steps * 1e3, "higher_is_better": False,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H}, {args.bounces} bounces, {args.spp} spp", "parallelism": f"contiguous row blocks x{world}, gathered on rank 0"},
-            "mrays_per_s": float(r_all.item()) / float(t_all.item()) / 1e6, "ranks": ranks, "world_size": dist.get_world_size() if dist is not None else 1,
+            "mrays_per_s": float(r_all.item()) / float(t_all.item()) / 1e6, "ranks": ranks, **group_view(dist),
             "identical_to_one_gpu_image": same}), flush=True)
     t.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
+
+
+def c1_gpu(pa, torch, frames=20):
+    """Configuration 1 on the GPU, the frame cpu_baseline_c1 times on the host cores: the sphere field on the ground plane
+    under the sky, 1920x1080, 8 bounces, 1 spp, one dispatch at a time (tests/test_gpu_configs.py compares every pixel of
+    this frame with the oracle's)."""
+    scene = pa.Scene("spheres"); sky = pa.procedural_sky(2048, 1024)
+    W, H = 1920, 1080
+    t = pa.PathTracer(torch.cuda.current_device())
+    t.load_scene(scene, sky); t.resize(W, H)
+    for k in range(3):
+        t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(k), spp=1, max_bounces=8))
+    t.sync(); t.stats()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        t.render(pa.make_params(scene, W, H, seed=pa.frame_seed(3 + k), spp=1, max_bounces=8))
+    t.sync()
+    dt = (time.perf_counter() - t0) / frames
+    st = t.stats()
+    t.close()
+    return {"value": st["rays"] / frames / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt * 1e3, "frames": frames,
+            "config": f"spheres scene ({len(scene.spheres)} spheres + ground plane + sky), {W}x{H}, 8 bounces, 1 spp, 1 GPU, one dispatch at a time"}
+
+
+def moving_camera_rate(pa, tr, scene, args, steps=6):
+    """Mrays/s of the headline workload, one dispatch at a time on the context `tr`, with the eye moving 0.02 units per
+    step (sideways and forwards): the block order of every dispatch comes from the previous position's costs."""
+    W, H = args.width, args.height
+    eye0 = np.array(scene.eye, np.float32)
+    def eye(k):
+        return eye0 + np.array([0.02 * k * 0.6, 0.0, 0.02 * k * 0.8], np.float32)
+    tr.render(pa.make_params(scene, W, H, seed=pa.frame_seed(0), spp=args.spp, max_bounces=args.bounces, eye=eye(0)))
+    tr.sync(); tr.stats()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        tr.render(pa.make_params(scene, W, H, seed=pa.frame_seed(1 + k), spp=args.spp, max_bounces=args.bounces, eye=eye(1 + k)))
+    tr.sync()
+    dt = time.perf_counter() - t0
+    st = tr.stats()
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "config": "the headline workload, one dispatch at a time, the eye advancing 0.02 units per step"}
 
 
 def stereo_frame_time(pa, torch, frames=30):

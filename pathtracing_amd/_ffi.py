@@ -156,7 +156,12 @@ _ptmaster = None
 def ptrace():
     global _ptrace
     if _ptrace is None:
-        _ptrace = _load(PTRACE_PATH, PTRACE_SYMBOLS, "libptrace")
+        # PTRACE_LIB: another build of libptrace.so (a measurement build, an A/B candidate) for this process only, so that
+        # comparisons never have to overwrite the installed library.  libptmaster still links against the installed one.
+        path = os.environ.get("PTRACE_LIB") or PTRACE_PATH
+        if not os.path.isabs(path):
+            path = os.path.join(_HERE, "csrc", path)
+        _ptrace = _load(path, PTRACE_SYMBOLS, "libptrace")
     return _ptrace
 
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -180,14 +181,204 @@ struct Builder {
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
+// The grid of a quantised node over the box pb: per axis the smallest power-of-two cell with 255 cells >= the extent.
+void node_grid(const Aabb &pb, float cell[3], uint8_t ebits[3])
+{
+    for (int a = 0; a < 3; a++) {
+        float ext = pb.hi[a] - pb.lo[a];
+        int e = -100;
+        if (ext > 0.0f && std::isfinite(ext)) {
+            (void)std::frexp(ext / 255.0f, &e);            // ext/255 = m * 2^e, m in [0.5, 1)
+            if (e < -100) e = -100;
+            while (pb.lo[a] + 255.0f * std::ldexp(1.0f, e) < pb.hi[a] && e < 100) e++;
+        }
+        cell[a] = std::ldexp(1.0f, e);
+        ebits[a] = (uint8_t)(e + 127);
+    }
+}
+// A child's planes on that grid, rounded outwards.
+void quantise(const Aabb &pb, const float cell[3], const Aabb &cb, uint8_t ql[3], uint8_t qh[3])
+{
+    for (int a = 0; a < 3; a++) {
+        float fl = std::floor((cb.lo[a] - pb.lo[a]) / cell[a]);
+        float fh = std::ceil((cb.hi[a] - pb.lo[a]) / cell[a]);
+        int l = (int)std::min(255.0f, std::max(0.0f, fl)), h = (int)std::min(255.0f, std::max(0.0f, fh));
+        while (l > 0 && pb.lo[a] + (float)l * cell[a] > cb.lo[a]) l--;      // outward rounding survives
+        while (h < 255 && pb.lo[a] + (float)h * cell[a] < cb.hi[a]) h++;    // the float arithmetic
+        ql[a] = (uint8_t)l; qh[a] = (uint8_t)h;
+    }
+}
+
+// Collapse to eight children per node (bvh.hpp, Bvh8Node): open the inner child with the largest area until there are
+// eight or none is left to open; give every child the slot whose corner direction (+-1, +-1, +-1) it lies farthest
+// along, seen from the node's centre (greedily, best pair first: Ylitie, Karras, Laine, "Efficient incoherent ray
+// traversal on GPUs through compressed wide BVHs", HPG 2017, section 4.2); number the inner children consecutively
+// and append the leaf children's primitives to the record order, both in slot order.
+// Which subtrees become the children of an eight-wide node, chosen to minimise the tree's SAH cost instead of by "open the
+// largest": C(n, i) = the cheapest way to stand for subtree n with at most i slots of a parent, a slot being an eight-wide
+// node (cost: its area times kWideNodeCost, plus its own eight slots' worth of subtree) or a single primitive (its area
+// times kWidePrimCost) - the dynamic program of Ylitie, Karras, Laine (HPG 2017, section 3), with one primitive per leaf:
+//   C(n, 1) = area(n) * kWideNodeCost + D(n, 8),    C(n, i) = min(C(n, 1), D(n, i)),    D(n, j) = min_k C(left, k) + C(right, j - k).
+// Filled bottom-up in one pass (a child's index is larger than its parent's); `take[j]` is the k of D(n, j), `node_at[i]`
+// whether C(n, i) is the node.  The greedy rule fills the bottom of the tree badly - sixteen primitives become one node of
+// eight two-primitive nodes instead of two nodes of eight - and every node costs a full visit however few children it has.
+constexpr float kWideNodeCost = 1.0f, kWidePrimCost = 0.35f;
+struct WideDp { float c[8]; uint8_t take[8]; uint8_t node_at; };
+
+void wide_dp(const std::vector<Tmp> &tmp, int32_t n_tmp, int32_t root, std::vector<WideDp> &dp, float prim_cost)
+{
+    dp.resize((size_t)n_tmp);
+    // areas relative to the root's, so that the sums stay finite whatever the scene's scale; a box without area (or with an
+    // infinite one) still costs a little per node: among equal costs the tree with fewer nodes wins
+    const float root_area = box_area(tmp[root].box);
+    const float scale = root_area > 0.0f && std::isfinite(root_area) ? 1.0f / root_area : 0.0f;
+    for (int32_t n = n_tmp - 1; n >= 0; n--) {
+        const Tmp &t = tmp[n];
+        WideDp &d = dp[(size_t)n];
+        float area = box_area(t.box) * scale;
+        if (!(area <= 1.0f)) area = 1.0f;
+        area += 1e-7f;
+        if (t.count) {                       // a primitive
+            for (int i = 0; i < 8; i++) { d.c[i] = area * prim_cost * (float)t.count; d.take[i] = 0; }
+            d.node_at = 0;
+            continue;
+        }
+        const WideDp &l = dp[(size_t)t.left], &r = dp[(size_t)t.right];
+        float dist[8];                       // dist[j - 1] = D(n, j), j >= 2
+        dist[0] = kInf;
+        for (int j = 2; j <= 8; j++) {
+            float best = kInf; int bk = 1;
+            for (int k = 1; k < j; k++) {
+                const float c = l.c[k - 1] + r.c[j - k - 1];
+                if (c < best) { best = c; bk = k; }
+            }
+            dist[j - 1] = best; d.take[j - 1] = (uint8_t)bk;
+        }
+        d.c[0] = area * kWideNodeCost + dist[7];
+        d.node_at = 1;
+        for (int i = 2; i <= 8; i++) {
+            if (d.c[0] <= dist[i - 1]) { d.c[i - 1] = d.c[0]; d.node_at |= (uint8_t)(1u << (i - 1)); }
+            else d.c[i - 1] = dist[i - 1];
+        }
+    }
+}
+// The slots subtree n takes when it may use at most i of them.
+void wide_slots(const std::vector<Tmp> &tmp, const std::vector<WideDp> &dp, int32_t n, int i, int32_t *kids, int &nk)
+{
+    const Tmp &t = tmp[n];
+    if (t.count || ((dp[(size_t)n].node_at >> (i - 1)) & 1)) { kids[nk++] = n; return; }
+    const int k = dp[(size_t)n].take[i - 1];
+    wide_slots(tmp, dp, t.left, k, kids, nk);
+    wide_slots(tmp, dp, t.right, i - k, kids, nk);
+}
+
+void collapse8(const std::vector<Tmp> &tmp, int32_t n_tmp, const std::vector<Ref> &refs, int32_t root, BvhResult &out)
+{
+    struct Item { int32_t tmp_index; uint32_t me; int depth; };
+    std::vector<Item> work;
+    bool greedy = false;
+    float prim_cost = kWidePrimCost;
+    if (const char *env = std::getenv("PTRACE_COLLAPSE")) { if (std::strcmp(env, "greedy") == 0) greedy = true; else if (std::atof(env) > 0.0) prim_cost = (float)std::atof(env); }
+    std::vector<WideDp> dp;
+    if (!greedy && !tmp[root].count) wide_dp(tmp, n_tmp, root, dp, prim_cost);
+    out.nodes8.clear(); out.order8.clear();
+    out.order8.reserve(refs.size());
+    out.nodes8.emplace_back();
+    int32_t root_kids[1] = {root};
+    work.push_back({tmp[root].count ? -1 : root, 0u, 1});
+    while (!work.empty()) {
+        const Item it = work.back(); work.pop_back();
+        int32_t kids[8]; int nk;
+        const Aabb *pbp;
+        if (it.tmp_index < 0) { kids[0] = root_kids[0]; nk = 1; pbp = &tmp[root].box; }     // the whole tree is one leaf
+        else {
+            const Tmp &t = tmp[it.tmp_index];
+            pbp = &t.box;
+            if (!greedy) {
+                nk = 0;
+                const int k = dp[(size_t)it.tmp_index].take[7];
+                wide_slots(tmp, dp, t.left, k, kids, nk);
+                wide_slots(tmp, dp, t.right, 8 - k, kids, nk);
+            } else { kids[0] = t.left; kids[1] = t.right; nk = 2; }
+            while (greedy && nk < 8) {
+                int best = -1; float best_area = -1.0f;
+                for (int k = 0; k < nk; k++)
+                    if (tmp[kids[k]].count == 0) {
+                        float ar = box_area(tmp[kids[k]].box);
+                        if (ar > best_area) { best_area = ar; best = k; }
+                    }
+                if (best < 0) break;
+                const int32_t open = kids[best];
+                kids[best] = tmp[open].left;
+                kids[nk++] = tmp[open].right;
+            }
+        }
+        const Aabb &pb = *pbp;
+        // ---- slots
+        int slot_of[8]; bool kid_done[8] = {false, false, false, false, false, false, false, false}, slot_used[8] = {false, false, false, false, false, false, false, false};
+        double cost[8][8];
+        for (int k = 0; k < nk; k++)
+            for (int sl = 0; sl < 8; sl++) {
+                double c = 0.0;
+                for (int a = 0; a < 3; a++) {
+                    double pc = 0.5 * ((double)pb.lo[a] + pb.hi[a]), kc = 0.5 * ((double)tmp[kids[k]].box.lo[a] + tmp[kids[k]].box.hi[a]);
+                    double d = kc - pc;
+                    if (!std::isfinite(d)) d = 0.0;
+                    c += ((sl >> a) & 1) ? d : -d;
+                }
+                cost[k][sl] = c;
+            }
+        for (int round = 0; round < nk; round++) {
+            int bk = -1, bs = -1;
+            for (int k = 0; k < nk; k++)
+                if (!kid_done[k])
+                    for (int sl = 0; sl < 8; sl++)
+                        if (!slot_used[sl] && (bk < 0 || cost[k][sl] > cost[bk][bs])) { bk = k; bs = sl; }
+            slot_of[bk] = bs; kid_done[bk] = true; slot_used[bs] = true;
+        }
+        int kid_in[8];
+        for (int sl = 0; sl < 8; sl++) kid_in[sl] = -1;
+        for (int k = 0; k < nk; k++) kid_in[slot_of[k]] = k;
+        // ---- the node
+        Bvh8Node nd; std::memset(&nd, 0, sizeof nd);
+        float cell[3]; uint8_t ebits[3];
+        node_grid(pb, cell, ebits);
+        for (int a = 0; a < 3; a++) nd.org[a] = pb.lo[a];
+        nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
+        nd.child_base = (uint32_t)out.nodes8.size();
+        nd.leaf_base = (uint32_t)out.order8.size();
+        uint32_t n_inner = 0;
+        for (int sl = 0; sl < 8; sl++) {
+            if (kid_in[sl] < 0) {
+                nd.qlo_x[sl] = nd.qlo_y[sl] = nd.qlo_z[sl] = 255; nd.qhi_x[sl] = nd.qhi_y[sl] = nd.qhi_z[sl] = 0;
+                continue;
+            }
+            const Tmp &c = tmp[kids[kid_in[sl]]];
+            uint8_t ql[3], qh[3];
+            quantise(pb, cell, c.box, ql, qh);
+            nd.qlo_x[sl] = ql[0]; nd.qlo_y[sl] = ql[1]; nd.qlo_z[sl] = ql[2];
+            nd.qhi_x[sl] = qh[0]; nd.qhi_y[sl] = qh[1]; nd.qhi_z[sl] = qh[2];
+            if (c.count) { nd.lmask |= 1u << sl; out.order8.push_back(refs[c.first].id); }     // one primitive per leaf
+            else { nd.imask |= (uint8_t)(1u << sl); n_inner++; }
+        }
+        out.nodes8[it.me] = nd;
+        out.depth8 = std::max(out.depth8, it.depth);
+        for (uint32_t k = 0; k < n_inner; k++) out.nodes8.emplace_back();
+        uint32_t next = nd.child_base;
+        for (int sl = 0; sl < 8; sl++)
+            if ((nd.imask >> sl) & 1) work.push_back({kids[kid_in[sl]], next++, it.depth + 1});
+    }
+    out.stack_need8 = out.depth8 + 1;
+}
+
 }  // namespace
 
-BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost)
+BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost, bool wide8)
 {
     BvhResult out;
     const uint32_t n = (uint32_t)boxes.size();
     if (n == 0) return out;
-    leaf_size = std::max(1, std::min(leaf_size, kMaxLeafPrims));
+    leaf_size = wide8 ? 1 : std::max(1, std::min(leaf_size, kMaxLeafPrims));
     if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     Builder b(boxes, leaf_size, threads);
     b.traversal_cost = traversal_cost;
@@ -230,6 +421,7 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
         }
         out.nodes4.push_back(w);
         out.depth4 = 1;
+        if (wide8) collapse8(tmp, b.next.load(), b.refs, root, out);
         return out;                      // a single leaf: nothing is ever stacked
     }
     out.nodes.reserve((size_t)b.next.load());
@@ -326,6 +518,7 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
     for (Bvh4Node &nd : out.nodes4)
         for (int k = 0; k < 4; k++)
             if (!((nd.valid >> k) & 1)) nd.child[k] = encode_leaf((uint32_t)boxes.size(), 1);
+    if (wide8) collapse8(tmp, b.next.load(), b.refs, root, out);
     return out;
 }
 

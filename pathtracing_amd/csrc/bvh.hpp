@@ -56,6 +56,29 @@ struct alignas(64) Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node layout");
 
+// Eight-wide device node, 80 bytes = five 16-byte loads.  Children whose boxes are quantised like Bvh4Node's; a child is an
+// inner node (its bit in `imask`), a leaf of exactly ONE primitive record (its bit in `lmask`) or absent (neither bit; the
+// slot holds the inside-out box qlo = 255, qhi = 0).  A node's inner children are consecutive in the node array from
+// `child_base`, its leaf children's records consecutive in the record array from `leaf_base`, both in slot order: the
+// child in slot s is node child_base + popcount(imask & ((1 << s) - 1)), or record leaf_base + popcount(lmask & ...).
+// Slots are assigned by position: bit a of the slot number says on which side of the node's centre the child lies along
+// axis a, so that for a ray whose direction has the sign bits `oct` (bit a set: negative along a) the order
+// slot ^ oct = 0, 1, ... 7 runs roughly front to back.  The traversal keeps (base, masks) pairs instead of links.
+//   q0 = (org.x, org.y, org.z, ex | ey << 8 | ez << 16 | imask << 24)
+//   q1 = (child_base, leaf_base, lmask, 0)
+//   q2 = (qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7])
+//   q3 = (qlo.z[0..3], qlo.z[4..7], qhi.x[0..3], qhi.x[4..7])
+//   q4 = (qhi.y[0..3], qhi.y[4..7], qhi.z[0..3], qhi.z[4..7])
+struct alignas(16) Bvh8Node {
+    float org[3];
+    uint8_t ex, ey, ez, imask;
+    uint32_t child_base, leaf_base;
+    uint32_t lmask;                   // low byte
+    uint32_t pad;
+    uint8_t qlo_x[8], qlo_y[8], qlo_z[8], qhi_x[8], qhi_y[8], qhi_z[8];
+};
+static_assert(sizeof(Bvh8Node) == 80, "Bvh8Node layout");
+
 struct BvhResult {
     std::vector<BvhNode> nodes;       // nodes[0] is the root (always an inner node) unless empty
     std::vector<Bvh4Node> nodes4;     // the same tree collapsed to four children per node; nodes4[0] is the root
@@ -66,13 +89,21 @@ struct BvhResult {
     // stacks all siblings of the child it follows (children - 1 per node).  stack_need2 <= depth <= kMaxDepth + 1; the
     // four-wide tree's figure depends on how the collapse fell and can approach 3 * kMaxDepth for lopsided trees.
     int stack_need2 = 0, stack_need4 = 0;
+    // The eight-wide tree (build_bvh with wide8 set; leaves hold one primitive each).  Its records follow order8, not
+    // `order`: the records of a node's leaf children are consecutive.  A ray holds at most one stack entry per level
+    // (what is left of the group of children it descended from) plus one: stack_need8 = depth8 + 1.
+    std::vector<Bvh8Node> nodes8;
+    std::vector<uint32_t> order8;
+    int depth8 = 0, stack_need8 = 0;
 };
 
 // boxes: one (already padded) box per primitive.  leaf_size <= kMaxLeafPrims.
 // threads <= 0: pick from hardware_concurrency (capped at 16).
 // traversal_cost: SAH cost of visiting a node, in primitive tests; ranges of <= leaf_size primitives become
 // leaves when that is estimated cheaper than splitting them.
-BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost = 0.5f);
+// wide8: also collapse the tree to eight children per node (nodes8, order8); the two-child tree is then built with one
+// primitive per leaf whatever leaf_size says, and `nodes4` / `order` describe that same tree.
+BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost = 0.5f, bool wide8 = false);
 
 // Reference splitting before the build: a large triangle's box is cut at spatial-median planes of the scene box into
 // several smaller boxes ("references"), each holding the part of the triangle on its side of the cuts, so that a long or

@@ -19,6 +19,7 @@ typedef pt_f3 f3;
 struct SceneDev {
     const float4 *nodes;       // 4 x float4 per BvhNode (two children per node)
     const uint4 *nodes4;       // 4 x uint4 per Bvh4Node (four children, 8-bit boxes); see bvh.hpp
+    const uint4 *nodes8;       // 5 x uint4 per Bvh8Node (eight children, 8-bit boxes, bases and masks instead of links)
     const float4 *prims;       // 3 x float4 per primitive record, BVH order
     const float4 *sphere_mat;  // 4 x float4 per sphere: (pos,r) (albedo,smoothness) (specular,0) (emission,0)
     const float4 *sky;         // RGBA32F texels, row 0 at v = 0
@@ -363,13 +364,157 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
         }
         sp += np;
     } else {
+#ifdef PT_COUNT_OVERFLOW   // measurement build: the node statistic counts the stack entries that went to the global overflow area
+        if (empty) (*empty) += (uint32_t)max(0, min(np, sp + np - ST::kLds));
+#endif
         if (np == 3) stack_push(st, sp, c3, key[3]);
         if (np >= 2) stack_push(st, sp, c2, key[2]);
         if (np >= 1) stack_push(st, sp, c1, key[1]);
     }
+#ifndef PT_COUNT_OVERFLOW
     if (empty && key[0] == 0xffffffffu) (*empty)++;   // -DPT_COUNT_EMPTY only
+#endif
     if (key[0] == 0xffffffffu) return stack_next(st, sp, tbest);
     return c0;
+}
+
+// ---- the eight-wide tree (bvh.hpp, Bvh8Node) ------------------------------------------------------------------------
+// A ray does not hold links but GROUPS: (base, mask) with mask = kind << 31 | member slots << 8 | hits, where `member
+// slots` is the node's imask (kind 1: inner children, base = child_base) or lmask (kind 0: leaves of one record each,
+// base = leaf_base) and `hits` says which of them the ray still has to visit - bit p standing for slot p ^ oct, so that
+// the lowest set bit is the child nearest along the ray's octant.  One visit tests eight boxes, keeps the hit leaves as
+// the current group (they are tested next), and leaves ONE stack entry at most behind: the inner children that were hit.
+// Nothing is sorted: the order comes from the slots the builder gave the children.
+struct Group { uint32_t base, mask; };
+constexpr uint32_t kInnerGroup = 0x80000000u;
+
+// Direction signs of the ray, bit a set = travelling towards -a.
+__device__ __forceinline__ uint32_t ray_octant(const RaySlabs &r)
+{
+    return (__float_as_uint(r.ix) >> 31) | ((__float_as_uint(r.iy) >> 31) << 1) | ((__float_as_uint(r.iz) >> 31) << 2);
+}
+// The group a new ray starts with: the root (node 0) as the only child of a node that does not exist.
+__device__ __forceinline__ Group root_group(uint32_t oct) { Group g = {0u, kInnerGroup | (1u << 8) | (1u << oct)}; return g; }
+
+// Stack of groups: entry e of thread t at lds[e * LDS_STRIDE + t] (one 8-byte access per entry), deeper entries as two
+// consecutive words of the global overflow area.
+template <int LDS_ENTRIES, int LDS_STRIDE>
+struct GroupStackT {
+    uint2 *lds;
+    uint32_t *overflow;
+    uint32_t stride;
+    static constexpr int kLds = LDS_ENTRIES, kStride = LDS_STRIDE;
+    static constexpr int kCapacity = LDS_ENTRIES + kStackOverflow / 2;
+};
+template <class ST>
+__device__ __forceinline__ void group_push(const ST &s, int &sp, Group g)
+{
+    if (sp < ST::kLds) s.lds[sp * ST::kStride] = make_uint2(g.base, g.mask);
+    else if (sp < ST::kCapacity) {
+        s.overflow[(size_t)(2 * (sp - ST::kLds)) * s.stride] = g.base;
+        s.overflow[(size_t)(2 * (sp - ST::kLds) + 1) * s.stride] = g.mask;
+    }
+    sp++;
+}
+// The next group to work on, or mask 0 when the stack is empty (the ray is finished).
+template <class ST>
+__device__ __forceinline__ Group group_pop(const ST &s, int &sp)
+{
+    Group g = {0u, 0u};
+    if (sp == 0) return g;
+    sp--;
+    if (sp < ST::kLds) { const uint2 v = s.lds[sp * ST::kStride]; g.base = v.x; g.mask = v.y; }
+    else if (sp < ST::kCapacity) {
+        g.base = s.overflow[(size_t)(2 * (sp - ST::kLds)) * s.stride];
+        g.mask = s.overflow[(size_t)(2 * (sp - ST::kLds) + 1) * s.stride];
+    }
+    return g;
+}
+// Takes the nearest member out of the group: its slot and its index (node or record).
+__device__ __forceinline__ uint32_t group_take(Group &g, uint32_t oct)
+{
+    const uint32_t p = (uint32_t)__builtin_ctz(g.mask);          // a group at hand always has a hit in its low byte
+    g.mask &= g.mask - 1u;
+    const uint32_t slot = p ^ oct;
+    return g.base + (uint32_t)__popc((g.mask >> 8) & 0xffu & ((1u << slot) - 1u));
+}
+__device__ __forceinline__ bool group_empty(const Group &g) { return (g.mask & 0xffu) == 0u; }
+
+// bit i -> bit i ^ oct in both bytes of a 16-bit word: three butterfly stages, each a shift by 0 for a clear bit of oct.
+__device__ __forceinline__ uint32_t octant_order(uint32_t x, uint32_t oct)
+{
+    const uint32_t s1 = oct & 1u, s2 = oct & 2u, s4 = oct & 4u;
+    x = ((x & 0x5555u) << s1) | ((x & 0xaaaau) >> s1);
+    x = ((x & 0x3333u) << s2) | ((x & 0xccccu) >> s2);
+    x = ((x & 0x0f0fu) << s4) | ((x & 0xf0f0u) >> s4);
+    return x;
+}
+
+// One inner node of the eight-wide tree: `cur` is an inner group with a hit.  On return `cur` is what the ray works on
+// next - the visited node's hit leaves, else its hit inner children, else the top of the stack - or has mask 0 (done).
+template <class ST>
+__device__ __forceinline__ void node_step8(const SceneDev &sc, Group &cur, const RaySlabs &r, float tbest, const ST &st, int &sp)
+{
+    const uint32_t oct = ray_octant(r);
+    const uint32_t node = group_take(cur, oct);
+    const uint4 *q = sc.nodes8 + (size_t)node * 5;
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    // what is left of the group the node came from: stored unconditionally, kept if it still has a hit
+    const bool keep = !group_empty(cur);
+    if (sp + 2 <= ST::kLds) { st.lds[sp * ST::kStride] = make_uint2(cur.base, cur.mask); sp += keep ? 1 : 0; }
+    else if (keep) group_push(st, sp, cur);
+    const uint32_t meta = q0.w;
+    const float sx = __builtin_ldexpf(r.ix, (int)(meta & 0xffu) - 127);
+    const float sy = __builtin_ldexpf(r.iy, (int)((meta >> 8) & 0xffu) - 127);
+    const float sz = __builtin_ldexpf(r.iz, (int)((meta >> 16) & 0xffu) - 127);
+    const float bx = __builtin_fmaf(__uint_as_float(q0.x), r.ix, r.ox);
+    const float by = __builtin_fmaf(__uint_as_float(q0.y), r.iy, r.oy);
+    const float bz = __builtin_fmaf(__uint_as_float(q0.z), r.iz, r.oz);
+    // per axis the planes the ray meets first: the low ones when it travels in +axis, else the high ones (two words: slots 0..3, 4..7)
+    const bool px = r.ix >= 0.0f, py = r.iy >= 0.0f, pz = r.iz >= 0.0f;
+    const uint32_t nxw[2] = {px ? q2.x : q3.z, px ? q2.y : q3.w}, fxw[2] = {px ? q3.z : q2.x, px ? q3.w : q2.y};
+    const uint32_t nyw[2] = {py ? q2.z : q4.x, py ? q2.w : q4.y}, fyw[2] = {py ? q4.x : q2.z, py ? q4.y : q2.w};
+    const uint32_t nzw[2] = {pz ? q3.x : q4.z, pz ? q3.y : q4.w}, fzw[2] = {pz ? q4.z : q3.x, pz ? q4.w : q3.y};
+    uint32_t hits = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int w = c >> 2, k = c & 3;
+        const float nx = __builtin_fmaf(ubyte_f(nxw[w], k), sx, bx), fx = __builtin_fmaf(ubyte_f(fxw[w], k), sx, bx);
+        const float ny = __builtin_fmaf(ubyte_f(nyw[w], k), sy, by), fy = __builtin_fmaf(ubyte_f(fyw[w], k), sy, by);
+        const float nz = __builtin_fmaf(ubyte_f(nzw[w], k), sz, bz), fz = __builtin_fmaf(ubyte_f(fzw[w], k), sz, bz);
+        const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+        const float tf = fminf(fminf(fminf(fx, fy), fz) * 1.000002f, tbest);   // an absent child holds an inside-out box: never entered
+        hits |= tn <= tf ? 1u << c : 0u;
+    }
+    const uint32_t imask = meta >> 24, lmask = q1.z & 0xffu;
+    const uint32_t ordered = octant_order((hits & imask) | ((hits & lmask) << 8), oct);
+    const uint32_t ih = ordered & 0xffu, lh = ordered >> 8;
+    const Group inner = {q1.x, kInnerGroup | (imask << 8) | ih}, leaves = {q1.y, (lmask << 8) | lh};
+    if (lh) {
+        if (sp + 1 <= ST::kLds) { st.lds[sp * ST::kStride] = make_uint2(inner.base, inner.mask); sp += ih ? 1 : 0; }
+        else if (ih) group_push(st, sp, inner);
+        cur = leaves;
+    } else if (ih) {
+        cur = inner;
+    } else {
+        cur = group_pop(st, sp);
+    }
+}
+
+// The records of a leaf group against the ray, two per round trip; then the next group (or mask 0).
+template <class ST>
+__device__ __forceinline__ void leaf_step8(const SceneDev &sc, Group &cur, f3 o, f3 d, uint32_t oct, float &tbest, int32_t &idbest,
+                                           uint32_t &recbest, const ST &st, int &sp, uint32_t &n_prims)
+{
+    const uint32_t r0 = group_take(cur, oct);
+    const bool two = !group_empty(cur);
+    const uint32_t r1 = two ? group_take(cur, oct) : r0;
+    const float4 *p = sc.prims + (size_t)r0 * 3, *q = sc.prims + (size_t)r1 * 3;
+    const float4 a0 = p[0], b0 = p[1], c0 = p[2], a1 = q[0], b1 = q[1], c1 = q[2];
+    intersect_record(a0, b0, c0, r0, o, d, tbest, idbest, recbest);
+    if (two) intersect_record(a1, b1, c1, r1, o, d, tbest, idbest, recbest);
+    n_prims += two ? 2u : 1u;
+    if (group_empty(cur)) cur = group_pop(st, sp);
 }
 
 template <int WIDE, class ST>
@@ -514,6 +659,27 @@ __device__ __forceinline__ void instanced_edges(const SceneDev &sc, int32_t id, 
     e1 = pt_sub3(v1, v0); e2 = pt_sub3(v2, v0);
 }
 
+// The per-lane stack a tree of WIDE children per node is walked with, over kWords * kBlock words of LDS per block.
+constexpr int kStack8Lds = 6;          // groups (8 bytes each) kept in LDS per lane: the 12 KB that kStackLds links take
+template <int WIDE> struct StackFor {
+    typedef Stack type;
+    static constexpr int kWords = kStackLds;
+    static __device__ __forceinline__ type make(uint32_t *lds_words, uint32_t *overflow, uint32_t stride)
+    {
+        type st = {lds_words + threadIdx.x, overflow, stride};
+        return st;
+    }
+};
+template <> struct StackFor<8> {
+    typedef GroupStackT<kStack8Lds, kBlock> type;
+    static constexpr int kWords = 2 * kStack8Lds;
+    static __device__ __forceinline__ type make(uint32_t *lds_words, uint32_t *overflow, uint32_t stride)
+    {
+        type st = {reinterpret_cast<uint2 *>(lds_words) + threadIdx.x, overflow, stride};
+        return st;
+    }
+};
+
 // Closest hit over spheres and triangles through the BVH.  tbest/idbest come in
 // holding the ground-plane result (or +inf / -1).
 template <int WIDE, class ST>
@@ -523,6 +689,15 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
     if (sc.n_nodes == 0) return;
     RaySlabs r = ray_slabs(o, d);
     int sp = 0;
+    if constexpr (WIDE == 8) {
+        const uint32_t oct = ray_octant(r);
+        Group cur = root_group(oct);
+        while (cur.mask) {
+            if (cur.mask & kInnerGroup) { node_step8(sc, cur, r, tbest, st, sp); n_nodes++; }
+            else leaf_step8(sc, cur, o, d, oct, tbest, idbest, recbest, st, sp, n_prims);
+        }
+        return;
+    } else {
     int32_t node = 0;
     if (sc.n_inst) {
         int cur_inst = -1;
@@ -535,6 +710,7 @@ __device__ __forceinline__ void traverse(const SceneDev &sc, f3 o, f3 d, float &
     while (node != kDoneNode) {
         if (node >= 0) { node = node_step<WIDE>(sc, node, r, tbest, st, sp); n_nodes++; }
         else node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, n_prims);
+    }
     }
 }
 
@@ -1123,15 +1299,15 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
     __shared__ uint32_t lds_stack[kLdsEntries * kBlock];
     __shared__ uint32_t lds_stack_t[kCull ? kLdsEntries * kBlock : 1];
 #else
-    typedef Stack PathStack;
-    __shared__ uint32_t lds_stack[kStackLds * kBlock];
+    typedef typename StackFor<WIDE>::type PathStack;
+    __shared__ __align__(8) uint32_t lds_stack[StackFor<WIDE>::kWords * kBlock];
 #endif
-    __shared__ float lds_save[3 * kBlock];   // node, sp, ray_work parked here during a shade phase
+    __shared__ float lds_save[3 * kBlock];   // node, sp, ray_work parked here during a shade phase (WIDE == 8: sp in the spare bits 16..23 of the group mask)
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x, n_threads = gridDim.x * kBlock;
 #if PT_STACK_T
     const PathStack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads, lds_stack_t + threadIdx.x};
 #else
-    const PathStack st = {lds_stack + threadIdx.x, a.stack_overflow + gtid, n_threads};
+    const PathStack st = StackFor<WIDE>::make(lds_stack, a.stack_overflow + gtid, n_threads);
 #endif
     const int lane = threadIdx.x & 63;
     const SceneDev &sc = a.sc;
@@ -1146,6 +1322,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
     RaySlabs rsl = {0, 0, 0, 0, 0, 0};
     float tbest = PT_INF; int32_t idbest = -1; uint32_t recbest = 0;
     int32_t node = kIdleNode; int sp = 0;
+    // WIDE == 8: the lane works on a group of children (node_step8): `node` is its base (>= 0) and `gmask` its mask - an
+    // inner group while bit 31 is set, else leaf records; the lane states (all negative) stay in `node`
+    uint32_t gmask = 0;
+    auto holds_inner = [&]() { if constexpr (WIDE == 8) return node >= 0 && (int32_t)gmask < 0; else return node >= 0; };
+    auto holds_leaf = [&]() { if constexpr (WIDE == 8) return node >= 0 && (int32_t)gmask >= 0; else return is_leaf_ref(node); };
     int cur_inst = -1;                    // INST: the instance the ray is walking through, -1 at the top level
     uint32_t ray_work = 0;                // nodes | prims << 16 of the current ray
     int shard = (int)(blockIdx.x % (uint32_t)a.n_shards);   // wave-uniform: which part of the frame this wave draws pixels from
@@ -1159,8 +1340,8 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #endif
 
     for (;;) {
-        const bool inner = node >= 0;
-        const bool leaf = is_leaf_ref(node);
+        const bool inner = holds_inner();
+        const bool leaf = holds_leaf();
         const bool waiting = node == kDoneNode || node == kIdleNode;
         const int n_inner = __popcll(__ballot(inner)), n_leaf = __popcll(__ballot(leaf)), n_wait = __popcll(__ballot(waiting));
         if (n_inner + n_leaf + n_wait == 0) break;
@@ -1180,7 +1361,9 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // LDS so that the shading code has those registers (the compiler cannot know they are idle).
             {
                 float *sv = lds_save + threadIdx.x;
-                sv[0 * kBlock] = as_f(node); sv[1 * kBlock] = as_f(INST ? sp | ((cur_inst + 1) << 8) : sp); sv[2 * kBlock] = as_f((int32_t)ray_work);
+                sv[0 * kBlock] = as_f(node); sv[2 * kBlock] = as_f((int32_t)ray_work);
+                if constexpr (WIDE == 8) sv[1 * kBlock] = as_f((int32_t)(gmask | ((uint32_t)sp << 16)));
+                else sv[1 * kBlock] = as_f(INST ? sp | ((cur_inst + 1) << 8) : sp);
             }
             const bool was_done = node == kDoneNode, was_idle = node == kIdleNode;
             bool new_ray = false, finished = false, no_more = false;
@@ -1351,6 +1534,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             {
                 const float *sv = lds_save + threadIdx.x;
                 node = as_i(sv[0 * kBlock]); sp = as_i(sv[1 * kBlock]); ray_work = (uint32_t)as_i(sv[2 * kBlock]);
+                if constexpr (WIDE == 8) { gmask = (uint32_t)sp & 0xff00ffffu; sp = (sp >> 16) & 0xff; }
                 if (INST) { cur_inst = (sp >> 8) - 1; sp &= 0xff; }
             }
             if (no_more) node = kDeadNode;
@@ -1375,6 +1559,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // The slab constants are not kept across the shade phase: every lane computes them here, the lanes that kept
             // their ray getting the values they had (the wave runs this code for the new rays anyway).
             rsl = INST && cur_inst >= 0 ? instance_slabs(sc, cur_inst, o, d) : ray_slabs(o, d);
+            if constexpr (WIDE == 8) { if (new_ray && node == 0) gmask = root_group(ray_octant(rsl)).mask; }   // a new ray starts at the root
             if (waiting) *ls3 = cnt;
             continue;
         }
@@ -1387,14 +1572,22 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
             // keep stepping while enough lanes hold an inner node; the other lanes' states cannot change
             // meanwhile, so only that one count is re-evaluated
             for (;;) {
+                if constexpr (WIDE == 8) {
+                    if (holds_inner()) {
+                        Group g = {(uint32_t)node, gmask};
+                        node_step8(sc, g, rsl, tbest, st, sp);
+                        node = g.mask ? (int32_t)g.base : kDoneNode; gmask = g.mask;
+                        ray_work++;
+                    }
+                } else
                 if (node >= 0) {
-#ifdef PT_COUNT_EMPTY   // measurement build: the node statistic counts only the visits that entered no child
+#if defined(PT_COUNT_EMPTY) || defined(PT_COUNT_OVERFLOW)   // measurement builds: the node statistic counts only the visits that entered no child / the stack entries that overflowed
                     if constexpr (WIDE == 4) { uint32_t e_ = 0; node = node_step4(sc, node, rsl, tbest, st, sp, &e_); ray_work += e_; } else
 #endif
                     { node = node_step<WIDE>(sc, node, rsl, tbest, st, sp); ray_work++; }
                     if (INST) resolve_instance_links(sc, node, o, d, cur_inst, rsl, st, sp);
                 }
-                const int still = __popcll(__ballot(node >= 0));
+                const int still = __popcll(__ballot(holds_inner()));
 #ifdef PT_PROFILE_PHASES
                 if (still >= vote_node) { ph_rounds[1]++; ph_lanes[1] += still; }
 #endif
@@ -1409,6 +1602,11 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 #endif
         if (leaf) {
             uint32_t np = 0;
+            if constexpr (WIDE == 8) {
+                Group g = {(uint32_t)node, gmask};
+                leaf_step8(sc, g, o, d, ray_octant(rsl), tbest, idbest, recbest, st, sp, np);
+                node = g.mask ? (int32_t)g.base : kDoneNode; gmask = g.mask;
+            } else
             if (INST) node = leaf_step_inst(sc, node, o, d, cur_inst, rsl, tbest, idbest, recbest, st, sp, np);
             else node = leaf_step(sc, node, o, d, tbest, idbest, recbest, st, sp, np);
             ray_work += np << 16;
@@ -1527,9 +1725,9 @@ template <int WIDE>
 __global__ __launch_bounds__(kBlock) void trace_rays_bvh_kernel(SceneDev sc, uint32_t *stack_overflow, const float *od, int n,
                                                                  int32_t *ids, float *ts)
 {
-    __shared__ uint32_t lds_stack[kStackLds * kBlock];
+    __shared__ __align__(8) uint32_t lds_stack[StackFor<WIDE>::kWords * kBlock];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const Stack st = {lds_stack + threadIdx.x, stack_overflow + i, gridDim.x * kBlock};
+    const typename StackFor<WIDE>::type st = StackFor<WIDE>::make(lds_stack, stack_overflow + i, gridDim.x * kBlock);
     if (i >= n) return;
     f3 o = pt_make3(od[i * 6 + 0], od[i * 6 + 1], od[i * 6 + 2]);
     f3 d = pt_make3(od[i * 6 + 3], od[i * 6 + 4], od[i * 6 + 5]);

@@ -24,6 +24,7 @@ struct RefitArgs {
     const float *slot_clip;   // 6 floats per slot or null: the part of the triangle's box this reference stands for,
     const float *build_matrices;   // valid while the object's matrix is bit for bit the one of the last full build
     uint4 *nodes4;            // Bvh4Node array
+    uint4 *nodes8;            // Bvh8Node array (refit_nodes8_kernel)
     float *node_box;          // 6 floats per node: exact union of its children's boxes
     const int32_t *level_nodes;   // node indices, deepest level first
     float pad;                // absolute padding of primitive boxes (from the last full build)
@@ -155,6 +156,63 @@ __global__ __launch_bounds__(kRefitBlock) void refit_nodes_kernel(const RefitArg
         }
     }
     *reinterpret_cast<Bvh4Node *>(a.nodes4 + (size_t)node * 4) = nd;
+}
+
+// The same for the eight-wide tree: the children of a node are its inner nodes from child_base on and the records of
+// its leaves (one each) from leaf_base on, both in slot order (bvh.hpp, Bvh8Node).
+__global__ __launch_bounds__(kRefitBlock) void refit_nodes8_kernel(const RefitArgs a, int first, int count)
+{
+    const int t = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (t >= count) return;
+    const int node = a.level_nodes[first + t];
+    Bvh8Node nd = *reinterpret_cast<const Bvh8Node *>(a.nodes8 + (size_t)node * 5);
+    float clo[8][3], chi[8][3];
+    float plo[3] = {PT_INF, PT_INF, PT_INF}, phi[3] = {-PT_INF, -PT_INF, -PT_INF};
+    uint32_t n_inner = 0, n_leaf = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float *src;
+        if ((nd.imask >> k) & 1) src = a.node_box + (size_t)(nd.child_base + n_inner++) * 6;
+        else if ((nd.lmask >> k) & 1) src = a.prim_box + (size_t)(nd.leaf_base + n_leaf++) * 6;
+        else continue;
+        for (int ax = 0; ax < 3; ax++) {
+            clo[k][ax] = src[ax]; chi[k][ax] = src[3 + ax];
+            plo[ax] = fminf(plo[ax], clo[k][ax]); phi[ax] = fmaxf(phi[ax], chi[k][ax]);
+        }
+    }
+    for (int ax = 0; ax < 3; ax++) { a.node_box[(size_t)node * 6 + ax] = plo[ax]; a.node_box[(size_t)node * 6 + 3 + ax] = phi[ax]; }
+    float cell[3];
+    uint8_t ebits[3];
+    for (int ax = 0; ax < 3; ax++) {
+        nd.org[ax] = plo[ax];
+        const float ext = phi[ax] - plo[ax];
+        int e = -100;
+        if (ext > 0.0f && ext < PT_INF) {
+            (void)frexpf(ext / 255.0f, &e);
+            if (e < -100) e = -100;
+            while (plo[ax] + 255.0f * ldexpf(1.0f, e) < phi[ax] && e < 100) e++;
+        }
+        cell[ax] = ldexpf(1.0f, e);
+        ebits[ax] = (uint8_t)(e + 127);
+    }
+    nd.ex = ebits[0]; nd.ey = ebits[1]; nd.ez = ebits[2];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint8_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};
+        if (((nd.imask | nd.lmask) >> k) & 1)
+            for (int ax = 0; ax < 3; ax++) {
+                const float fl = floorf((clo[k][ax] - plo[ax]) / cell[ax]), fh = ceilf((chi[k][ax] - plo[ax]) / cell[ax]);
+                int l = (int)fminf(255.0f, fmaxf(0.0f, fl)), h = (int)fminf(255.0f, fmaxf(0.0f, fh));
+                if (!(fl == fl)) l = 0;                        // an infinite or NaN extent: the whole grid
+                if (!(fh == fh)) h = 255;
+                while (l > 0 && plo[ax] + (float)l * cell[ax] > clo[k][ax]) l--;
+                while (h < 255 && plo[ax] + (float)h * cell[ax] < chi[k][ax]) h++;
+                ql[ax] = (uint8_t)l; qh[ax] = (uint8_t)h;
+            }
+        nd.qlo_x[k] = ql[0]; nd.qlo_y[k] = ql[1]; nd.qlo_z[k] = ql[2];
+        nd.qhi_x[k] = qh[0]; nd.qhi_y[k] = qh[1]; nd.qhi_z[k] = qh[2];
+    }
+    *reinterpret_cast<Bvh8Node *>(a.nodes8 + (size_t)node * 5) = nd;
 }
 
 }  // namespace ptrace

@@ -152,9 +152,9 @@ __global__ __launch_bounds__(kScreenBlockX * kScreenBlockY) void taa_kernel(cons
 template <int WIDE>
 __global__ __launch_bounds__(kBlock) void primary_kernel(const RenderArgs a, int what, int skip_lo, int skip_hi)
 {
-    __shared__ uint32_t lds_stack[kStackLds * kBlock];
+    __shared__ __align__(8) uint32_t lds_stack[StackFor<WIDE>::kWords * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, n_threads = gridDim.x * kBlock;
-    const Stack st = {lds_stack + threadIdx.x, a.stack_overflow + tid, n_threads};
+    const typename StackFor<WIDE>::type st = StackFor<WIDE>::make(lds_stack, a.stack_overflow + tid, n_threads);
     const int lane = threadIdx.x & 63;
     uint32_t cn = 0, cp = 0, rays = 0;
     // the grid is capped (the stack overflow area is per resident thread); a thread takes every n_threads-th pixel

@@ -80,6 +80,9 @@ struct pt_context {
 
     // device scene
     uint4 *d_nodes4 = nullptr;
+    uint4 *d_nodes8 = nullptr;        // the eight-wide tree (option bvh_width 8); the records then follow its order, and the other trees are not kept
+    int n_nodes8 = 0, stack_need8 = 0;
+    bool walk8 = false;               // the last build made the eight-wide tree and a lane's stack holds it
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_sphere_mat = nullptr, *d_sky = nullptr;
     int n_nodes4 = 0, bvh_width = 4;
     int stack_need4 = 0;                           // most stack entries a ray can hold in the four-wide tree of the last build
@@ -133,6 +136,7 @@ struct pt_context {
     int vote_shade_few = 52;               // the shade vote of dispatches with one or two samples per pixel (launch_path)
     int sched_blocks_per_cu = 0, sched_ext_blocks_per_cu = 0;   // resident blocks per CU of path_sched_kernel / path_sched_mat_kernel
     int sched_inst_blocks_per_cu = 0;                           // and of path_sched_inst_kernel
+    int sched8_blocks_per_cu = 0, sched8_ext_blocks_per_cu = 0; // and of the two kernels' eight-wide instantiations
     int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
     int reuse_primary = 0;                 // option "reuse_primary_hit"
     int backend = 0;                       // 0 = path_sched_kernel (one ray per lane), 1 = wavefront stages, 2 = path_pool_kernel (ray pool per wave)
@@ -225,7 +229,13 @@ thread_local std::string g_create_error;
 // depth is bounded by kMaxDepth, so it always fits.
 int tree_width(const pt_context *ctx)
 {
-    return ctx->bvh_width == 4 && ctx->stack_need4 <= ctx->stack_limit ? 4 : 2;
+    if (ctx->walk8) return 8;         // set by a build under option bvh_width 8 whose tree fits a lane's stack of groups
+    return ctx->bvh_width != 2 && ctx->stack_need4 <= ctx->stack_limit ? 4 : 2;
+}
+// Groups a lane's stack holds when it walks the eight-wide tree (pt_device.hpp, GroupStackT); PTRACE_STACK_LIMIT lowers it too.
+int group_stack_limit(const pt_context *ctx)
+{
+    return std::min(ctx->stack_limit, kStack8Lds + kStackOverflow / 2);
 }
 
 int fail(pt_context *ctx, int code, const std::string &msg)
@@ -632,7 +642,14 @@ int rebuild_scene(pt_context *ctx)
     const size_t nI = inst_object.size();
     const size_t nRefs = ref_prim.size();                  // top-level references: nR of primitives, then one per instance
 
-    BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct);
+    const bool want8 = ctx->bvh_width == 8 && nI == 0;
+    BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct, want8);
+    // the eight-wide tree is walked if a lane's stack holds it; a tree too deep for that (a degenerate chain) is walked as the
+    // two-child tree of the same build, whose records follow the other order
+    const bool walk8 = want8 && !bvh.nodes8.empty() && bvh.stack_need8 <= group_stack_limit(ctx);
+    const std::vector<uint32_t> &order = walk8 ? bvh.order8 : bvh.order;
+    if (walk8) { bvh.nodes.clear(); bvh.nodes4.clear(); }
+    else { bvh.nodes8.clear(); }
     auto t_built = std::chrono::steady_clock::now();
     if (nI) {
         // entering an instance costs the exit marker, and a top-level leaf can stack a link per instance record it holds
@@ -654,7 +671,7 @@ int rebuild_scene(pt_context *ctx)
     if (n_recs >= (1u << 27)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^27 primitive records");
     std::vector<float4> recs((keep_mesh_trees ? nRefs + 1 : n_recs) * 3, make_float4(0, 0, 0, 0));
     for (size_t slot = 0; slot < nRefs; slot++) {
-        uint32_t prim = ref_prim[bvh.order[slot]];
+        uint32_t prim = ref_prim[order[slot]];
         if (prim >= nP) {                                  // an instance: kind 2, b.x = its index
             const int32_t ii = (int32_t)(prim - nP), two = 2;
             float iif, kind; std::memcpy(&iif, &ii, 4); std::memcpy(&kind, &two, 4);
@@ -687,7 +704,7 @@ int rebuild_scene(pt_context *ctx)
                 if (nd.child[k] >= 0 || !((nd.valid >> k) & 1)) continue;      // an unused slot links to the record past the last one
                 const uint32_t enc = (uint32_t)~nd.child[k];
                 if ((enc & 7u) != 0) continue;
-                const uint32_t prim = ref_prim[bvh.order[enc >> 3]];
+                const uint32_t prim = ref_prim[order[enc >> 3]];
                 if (prim >= nP) nd.child[k] = (int32_t)~(kInstanceBit | (uint32_t)(prim - nP));
             }
     }
@@ -759,7 +776,7 @@ int rebuild_scene(pt_context *ctx)
     ctx->inst_node_cap = nI ? node_cap : 0; ctx->inst_rec_cap = nI ? rec_cap : 0;
     // ---- what a later refit needs: per slot its source triangle, the object-space vertices, the tree's levels
     ctx->refit_ready = false;
-    if (ctx->refit && !bvh.nodes4.empty() && nI == 0) {
+    if (ctx->refit && (!bvh.nodes4.empty() || walk8) && nI == 0) {
         std::vector<int32_t> tri_obj(tris.size()), tri_i0(tris.size()), tri_i1(tris.size()), tri_i2(tris.size());
         size_t j = 0;
         for (size_t o = 0; o < ctx->objects.size(); o++) {
@@ -772,21 +789,30 @@ int rebuild_scene(pt_context *ctx)
         std::vector<int4> slot_src(nR);
         std::vector<float> slot_clip(clip.empty() ? 0 : nR * 6);
         for (size_t slot = 0; slot < nR; slot++) {
-            uint32_t prim = ref_prim[bvh.order[slot]];
+            uint32_t prim = ref_prim[order[slot]];
             if ((int)prim < nS) slot_src[slot] = make_int4(-1, 0, 0, 0);
             else { size_t t = prim - nS; slot_src[slot] = make_int4(tri_obj[t], tri_i0[t], tri_i1[t], tri_i2[t]); }
-            if (!clip.empty()) { std::memcpy(&slot_clip[slot * 6], clip[bvh.order[slot]].lo, 12); std::memcpy(&slot_clip[slot * 6 + 3], clip[bvh.order[slot]].hi, 12); }
+            if (!clip.empty()) { std::memcpy(&slot_clip[slot * 6], clip[order[slot]].lo, 12); std::memcpy(&slot_clip[slot * 6 + 3], clip[order[slot]].hi, 12); }
         }
         // nodes are stored parents first, so one forward pass gives every node its level
-        const size_t nN = bvh.nodes4.size();
+        const size_t nN = walk8 ? bvh.nodes8.size() : bvh.nodes4.size();
         std::vector<int> level(nN, 0);
         int max_level = 0;
-        for (size_t n = 0; n < nN; n++)
+        for (size_t n = 0; n < nN; n++) {
+            if (walk8) {
+                const Bvh8Node &nd = bvh.nodes8[n];
+                for (int k = 0, kids = __builtin_popcount(nd.imask); k < kids; k++) {
+                    level[nd.child_base + (uint32_t)k] = level[n] + 1;
+                    max_level = std::max(max_level, level[n] + 1);
+                }
+                continue;
+            }
             for (int k = 0; k < 4; k++)
                 if (((bvh.nodes4[n].valid >> k) & 1) && bvh.nodes4[n].child[k] >= 0) {
                     level[bvh.nodes4[n].child[k]] = level[n] + 1;
                     max_level = std::max(max_level, level[n] + 1);
                 }
+        }
         std::vector<int> count(max_level + 2, 0);
         for (size_t n = 0; n < nN; n++) count[max_level - level[n] + 1]++;       // deepest level first
         for (int l = 0; l <= max_level; l++) count[l + 1] += count[l];
@@ -814,6 +840,8 @@ int rebuild_scene(pt_context *ctx)
         if ((rc = h2d(ctx, ctx->d_prims, recs.data(), recs.size() * sizeof(float4)))) return rc;
     }
     if (!nI && (rc = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode)))) return rc;   // a two-level scene is never walked as a two-child tree
+    if ((rc = upload(ctx, ctx->d_nodes8, bvh.nodes8.data(), bvh.nodes8.size() * sizeof(Bvh8Node)))) return rc;
+    ctx->walk8 = walk8; ctx->n_nodes8 = (int)bvh.nodes8.size(); ctx->stack_need8 = bvh.stack_need8;
     if (nI) free_dev(ctx->d_nodes);
 #ifdef PT_NODES_SOA
     {
@@ -837,9 +865,9 @@ int rebuild_scene(pt_context *ctx)
     ctx->n_spheres = nS;
     ctx->stack_need4 = bvh.stack_need4;
     static_assert(kMaxDepth + 1 <= kStackLds + kStackOverflow, "the two-child tree must always fit the traversal stack");
-    ctx->stats.bvh_nodes = tree_width(ctx) == 4 ? ctx->n_nodes4 : ctx->n_nodes;
+    ctx->stats.bvh_nodes = walk8 ? ctx->n_nodes8 : tree_width(ctx) == 4 ? ctx->n_nodes4 : ctx->n_nodes;
     ctx->stats.bvh_prims = ctx->n_prims;
-    ctx->stats.bvh_depth = tree_width(ctx) == 4 ? bvh.depth4 : bvh.depth;
+    ctx->stats.bvh_depth = walk8 ? bvh.depth8 : tree_width(ctx) == 4 ? bvh.depth4 : bvh.depth;
     ctx->stats.bvh_build_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING"))
@@ -890,10 +918,10 @@ int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
 SceneDev scene_dev(const pt_context *ctx)
 {
     SceneDev sc;
-    sc.nodes = ctx->d_nodes; sc.nodes4 = ctx->d_nodes4; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
+    sc.nodes = ctx->d_nodes; sc.nodes4 = ctx->d_nodes4; sc.nodes8 = ctx->d_nodes8; sc.prims = ctx->d_prims; sc.sphere_mat = ctx->d_sphere_mat; sc.sky = ctx->d_sky;
     sc.mesh_mat = ctx->d_mesh_mat;
     sc.sky_w = ctx->sky_w; sc.sky_h = ctx->sky_h;
-    sc.n_nodes = ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres; sc.n_nodes4 = ctx->n_nodes4;
+    sc.n_nodes = ctx->walk8 ? ctx->n_nodes8 : ctx->n_nodes; sc.n_prims = ctx->n_prims; sc.n_spheres = ctx->n_spheres; sc.n_nodes4 = ctx->n_nodes4;
     sc.inst = ctx->d_inst; sc.objects = ctx->d_objects; sc.indices = ctx->d_indices; sc.vertices = ctx->d_vertices; sc.matrices = ctx->d_matrices;
     sc.n_inst = ctx->n_inst; sc.n_top_records = ctx->n_top_records;
     float half = 0.0f;
@@ -1068,8 +1096,12 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->sched_ext_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_inst_kernel, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched_inst_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_kernel<8>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched8_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_mat_kernel<8>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched8_ext_blocks_per_cu = std::max(1, bpc);
     if (std::getenv("PTRACE_BUILD_TIMING"))
-        std::fprintf(stderr, "resident blocks per CU: path_sched_kernel %d, path_sched_mat_kernel %d, path_sched_inst_kernel %d\n", ctx->sched_blocks_per_cu, ctx->sched_ext_blocks_per_cu, ctx->sched_inst_blocks_per_cu);
+        std::fprintf(stderr, "resident blocks per CU: path_sched_kernel %d, path_sched_mat_kernel %d, path_sched_inst_kernel %d, eight-wide %d and %d\n", ctx->sched_blocks_per_cu, ctx->sched_ext_blocks_per_cu, ctx->sched_inst_blocks_per_cu, ctx->sched8_blocks_per_cu, ctx->sched8_ext_blocks_per_cu);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->pool_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_mat_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
@@ -1081,7 +1113,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
         else std::fprintf(stderr, "libptrace: PTRACE_BACKEND=%s ignored (sched | wavefront | pool)\n", env);
     }
     if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
-    if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : 4;
+    if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : std::atoi(env) == 8 ? 8 : 4;
     if (const char *env = std::getenv("PTRACE_BLOCK_ORDER")) ctx->block_order = std::atoi(env) != 0;
     if (const char *env = std::getenv("PTRACE_SPLIT")) ctx->split_budget = std::max(0.0f, std::min(4.0f, (float)std::atof(env)));
     if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
@@ -1108,7 +1140,7 @@ void pt_destroy(pt_context *ctx)
     // renders may still be running on the caller's stream (pt_set_stream): they use the buffers freed below
     if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky);
+    free_dev(ctx->d_nodes); free_dev(ctx->d_nodes4); free_dev(ctx->d_nodes8); free_dev(ctx->d_prims); free_dev(ctx->d_sphere_mat); free_dev(ctx->d_sky);
     free_dev(ctx->own_result); free_dev(ctx->own_conv); free_dev(ctx->own_ids); free_dev(ctx->own_result2);
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds); free_dev(ctx->own_display);
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
@@ -1205,7 +1237,7 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
             objects[o].indices_count != ctx->objects[o].indices_count)
             return fail(ctx, PT_ERR_INVALID, "pt_update_transforms: index ranges differ from pt_set_meshes");
     ctx->objects.assign(objects, objects + n_objects);
-    if (!ctx->refit || !ctx->refit_ready || ctx->scene_dirty || tree_width(ctx) != 4 || n_objects == 0) {
+    if (!ctx->refit || !ctx->refit_ready || ctx->scene_dirty || tree_width(ctx) == 2 || n_objects == 0) {
         ctx->scene_dirty = true;      // full build at the next render
         return PT_OK;
     }
@@ -1223,19 +1255,21 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_matrices, ctx->h_matrices, (size_t)n_objects * 64, hipMemcpyHostToDevice, ctx->stream));
     RefitArgs ra;
     ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
-    ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
+    ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.nodes8 = ctx->d_nodes8; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
     ra.pad = ctx->box_pad; ra.sphere_slack2 = ctx->sphere_slack2; ra.reach = ctx->sphere_reach; ra.n_prims = ctx->n_slots;
     ra.slot_clip = ctx->d_slot_clip; ra.build_matrices = ctx->d_build_matrices;
     hipLaunchKernelGGL(refit_prims_kernel, dim3((ctx->n_slots + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra);
     for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
         const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
-        if (count > 0)
+        if (count > 0 && ctx->walk8)
+            hipLaunchKernelGGL(refit_nodes8_kernel, dim3((count + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra, first, count);
+        else if (count > 0)
             hipLaunchKernelGGL(refit_nodes_kernel, dim3((count + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra, first, count);
     }
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventRecord(ctx->ev_refit, ctx->stream));
     ctx->refit_in_flight = true;
-    ctx->bvh2_stale = true;
+    ctx->bvh2_stale = !ctx->walk8;
     // scene bounds after the move, from the objects' object-space boxes (an over-estimate is fine: it feeds ensure_scene)
     for (int k = 0; k < 3; k++) { ctx->scene_lo[k] = ctx->spheres_lo[k]; ctx->scene_hi[k] = ctx->spheres_hi[k]; }
     for (int o = 0; o < n_objects && o < (int)ctx->object_box.size(); o++) {
@@ -1352,7 +1386,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     const bool instanced = ctx->n_inst > 0;        // two-level scene: path_sched_inst_kernel, whatever the backend option says
     const bool extended = instanced || ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
     // the wavefront stages pack a path's bounce count into 8 bits (pt_wavefront.hpp): longer paths go to the scheduled kernel
-    if (ctx->backend == 1 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary && a.maxb <= 255) return render_wavefront(ctx, a);
+    const int width = tree_width(ctx);                // 8: walked by the scheduled kernel only, whatever the backend option says
+    if (ctx->backend == 1 && width != 8 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary && a.maxb <= 255) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
     {
         // Few samples per pixel: pixels are claimed often, and one counter would serialise the claims at the L2.  Many
@@ -1402,7 +1437,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
             return PT_OK;
         }
     } after{ctx, a, want_order, key};
-    if (ctx->backend == 2 && !instanced) {
+    if (ctx->backend == 2 && !instanced && width != 8) {
         // one wave per block, kPoolK * 64 ray slots per wave
         constexpr int P = 64 * kPoolK;
         const int fit = extended ? ctx->pool_ext_blocks_per_cu : ctx->pool_blocks_per_cu;
@@ -1432,7 +1467,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         return after.done();
     }
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-    const int fit = instanced ? ctx->sched_inst_blocks_per_cu : extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
+    const int fit = instanced ? ctx->sched_inst_blocks_per_cu : width == 8 ? (extended ? ctx->sched8_ext_blocks_per_cu : ctx->sched8_blocks_per_cu)
+                              : extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
     const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, fit) : fit;
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * per_cu);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
@@ -1444,10 +1480,12 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     if (instanced) {
         hipLaunchKernelGGL(path_sched_inst_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else if (extended) {
-        if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        if (width == 8) hipLaunchKernelGGL(path_sched_mat_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else if (width == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_mat_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
-        if (tree_width(ctx) == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        if (width == 8) hipLaunchKernelGGL(path_sched_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else if (width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     }
     PT_HIP(ctx, hipGetLastError());
@@ -1464,7 +1502,8 @@ static int launch_primary(pt_context *ctx, RenderArgs &a, int what, int x0, int 
     const int grid = (int)std::min<int64_t>(((int64_t)a.total_items + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8 * 4);
     if ((rc = ensure_stack_overflow(ctx, (size_t)grid * kBlock))) return rc;
     a.stack_overflow = ctx->d_stack_ovf;
-    if (tree_width(ctx) == 4) hipLaunchKernelGGL(primary_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
+    if (tree_width(ctx) == 8) hipLaunchKernelGGL(primary_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
+    else if (tree_width(ctx) == 4) hipLaunchKernelGGL(primary_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
     else hipLaunchKernelGGL(primary_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, what, skip_lo, skip_hi);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
@@ -1681,7 +1720,8 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         return PT_OK;
     }
     if (std::strcmp(name, "bvh_width") == 0) {
-        if (value != 2 && value != 4) return fail(ctx, PT_ERR_INVALID, "pt_set_option: bvh_width must be 2 or 4");
+        if (value != 2 && value != 4 && value != 8) return fail(ctx, PT_ERR_INVALID, "pt_set_option: bvh_width must be 2, 4 or 8");
+        if ((value == 8) != (ctx->bvh_width == 8)) ctx->scene_dirty = true;     // the eight-wide tree has its own record order
         ctx->bvh_width = value;
         return PT_OK;
     }
@@ -1847,6 +1887,8 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     SceneDev sc = scene_dev(ctx);
     if (brute_force)
         hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_od, n_rays, d_id, d_t);
+    else if (tree_width(ctx) == 8)
+        hipLaunchKernelGGL(trace_rays_bvh_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     else if (tree_width(ctx) == 4)
         hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, ctx->d_stack_ovf, d_od, n_rays, d_id, d_t);
     else
@@ -1886,6 +1928,8 @@ int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
     const SceneDev sc = scene_dev(ctx);
     if (brute_force)
         hipLaunchKernelGGL(trace_rays_brute_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_od, n_rays, d_id, d_t);
+    else if (tree_width(ctx) == 8)
+        hipLaunchKernelGGL(trace_rays_bvh_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_stack, d_od, n_rays, d_id, d_t);
     else if (tree_width(ctx) == 4)
         hipLaunchKernelGGL(trace_rays_bvh_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, sc, d_stack, d_od, n_rays, d_id, d_t);
     else

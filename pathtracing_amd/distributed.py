@@ -58,7 +58,9 @@ class ShardedAccumulator:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         weighted = frame * float(samples) if samples != 1 else frame
         w = torch.tensor([float(samples if weight is None else weight)], dtype=torch.float64, device=frame.device)
-        if world > 1:
+        # a process group of one rank still runs the collectives (the identity then): that is how a one-GPU box rehearses
+        # the very calls an N-GPU job makes
+        if world > 1 or dist.is_initialized():
             if weighted is frame:
                 weighted = frame.clone()
             (reduce or dist.reduce)(weighted, dst=self.dst, op=dist.ReduceOp.SUM, group=group)

@@ -1,6 +1,6 @@
 """The benchmark configurations at their full sizes, each against the oracle: the sphere field (whole frame, exhaustive
-loop), the 260 k-triangle scene with GGX surfaces (a tile, 16 samples), the 10 M-triangle scene as a 4K stereo pair with
-its depth output fed to a reprojection frame."""
+loop), the 70 k-triangle mesh (a tile of the 1080p frame, 16 samples), the 260 k-triangle scene with GGX surfaces (a
+tile, 16 samples), the 10 M-triangle scene as a 4K stereo pair with its depth output fed to a reprojection frame."""
 import numpy as np
 import pytest
 
@@ -29,6 +29,33 @@ def test_sphere_field_full_frame_against_the_exhaustive_loop(tracer):
     assert _same(g, c)
     assert st["rays"] == cst["rays"] and st["paths"] == W * H
     assert (gid > 0).mean() > 0.2 and (gid == 0).mean() > 0.2 and (gid < 0).mean() > 0.2    # spheres, plane and sky all in view
+
+
+def test_mesh_70k_tile_at_full_size(tracer):
+    """Configuration 2 as stated: the ~70 k-triangle mesh through the tree, 1920x1080, 8 bounces, 16 samples in one
+    dispatch - the settings bench.py quotes a rate for.  A 160x90 tile of that frame with the mesh in it against the
+    oracle (its own tree), hit ids and bits; the whole frame rendered at once must show the same tile."""
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(512, 256)
+    W, H = 1920, 1080
+    tracer.load_scene(s, sky); tracer.set_mesh_materials(None); tracer.resize(W, H)
+    whole = pa.make_params(s, W, H, seed=pa.frame_seed(2), spp=16, max_bounces=8)
+    tracer.render(whole)
+    full = tracer.read_result(); full_ids = tracer.read_hit_ids()
+    # the tile with the most mesh pixels among a coarse grid of candidates
+    best, tile = -1, None
+    for y0 in range(0, H - 90 + 1, 90):
+        for x0 in range(0, W - 160 + 1, 160):
+            n = int((full_ids[y0:y0 + 90, x0:x0 + 160] > len(s.spheres)).sum())
+            if n > best:
+                best, tile = n, (x0, y0, 160, 90)
+    ys, xs = slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2])
+    assert best > 0.3 * 160 * 90
+    p = pa.make_params(s, W, H, seed=pa.frame_seed(2), spp=16, max_bounces=8, tile=tile)
+    c, cid, cst = po.Oracle.from_scene(s, sky, accel=True).render(p, W, H, threads=16)
+    assert (full_ids[ys, xs] == cid[ys, xs]).all()
+    assert _same(full[ys, xs], c[ys, xs])
+    tracer.resize(W, H); tracer.stats(); tracer.render(p)            # and dispatched as a tile: same pixels, the oracle's ray count
+    assert _same(tracer.read_result()[ys, xs], c[ys, xs]) and tracer.stats()["rays"] == cst["rays"]
 
 
 def test_ggx_hall_tile_at_full_size(tracer):

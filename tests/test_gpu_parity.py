@@ -1322,8 +1322,10 @@ def test_large_triangles_are_split_into_references(tracer, sky_small):
             seen[percent] = (st["nodes_visited"], st["prims_tested"], st["bvh_nodes"], st["bvh_prims"])
         assert seen[0][3] == seen[30][3] == seen[400][3]                     # primitives, not references
         assert seen[30][2] > seen[0][2] and seen[400][2] > seen[30][2]       # more references, more nodes
-        assert seen[30][0] < 0.85 * seen[0][0] and seen[30][1] < 0.6 * seen[0][1], seen
-        assert seen[400][0] < 0.7 * seen[0][0] and seen[400][1] < 0.2 * seen[0][1], seen
+        # (the eight-wide tree tests every primitive's own box in its parent: fewer visits to begin with, a smaller share to win)
+        wide8 = tracer.variant.endswith("bvh8")
+        assert seen[30][0] < (0.95 if wide8 else 0.85) * seen[0][0] and seen[30][1] < 0.6 * seen[0][1], seen
+        assert seen[400][0] < (0.8 if wide8 else 0.7) * seen[0][0] and seen[400][1] < 0.2 * seen[0][1], seen
         tracer.set_option("split_percent", 30)
         tracer.stats()
         tracer.render(p); before = tracer.stats()["nodes_visited"]
@@ -1448,3 +1450,34 @@ def test_instances_share_one_tree(tracer, sky_small):
         _assert_same_image(tracer.read_result(), cd, "instances, _Depth")
     finally:
         tracer.set_option("instancing", 0); tracer.set_mesh_materials(None)
+
+
+def test_wavefront_stages_match_golden_vectors_and_oracle(sky_small):
+    """The separate trace / shade stages with compaction and regeneration (pt_set_option("backend", 1)): the committed golden
+    vectors, and the 70 k-triangle mesh against the oracle."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fixture_64x36.npz"))
+    with pa.PathTracer(0) as t:
+        t.set_option("backend", 1)
+        s = pa.Scene("fixture")
+        t.load_scene(s, pa.procedural_sky(128, 64))
+        W, H = 64, 36
+        t.resize(W, H)
+        for name, kw in {"spp1_b4": dict(spp=1, max_bounces=4), "spp16_b8": dict(spp=16, max_bounces=8)}.items():
+            t.stats()
+            t.render(pa.make_params(s, W, H, seed=0.5, **kw))
+            _assert_same_image(t.read_result(), g[name], "wavefront " + name)
+            assert (t.read_hit_ids() == g["ids"]).all()
+            st = t.stats()
+            assert [st["rays"], st["paths"]] == [g[name + "_rays"][0], g[name + "_rays"][2]]
+        for width in (4, 2):
+            t.set_option("bvh_width", width)
+            m = pa.Scene("blob70k")
+            t.load_scene(m, sky_small)
+            W, H = 128, 72
+            t.resize(W, H)
+            p = pa.make_params(m, W, H, seed=0.5, spp=3, max_bounces=8)
+            t.stats(); t.render(p)
+            c, cid, cst = po.Oracle.from_scene(m, sky_small, accel=True).render(p, W, H, threads=8)
+            assert (t.read_hit_ids() == cid).all()
+            _assert_same_image(t.read_result(), c, f"wavefront blob70k width {width}")
+            assert t.stats()["rays"] == cst["rays"]

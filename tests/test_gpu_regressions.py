@@ -90,6 +90,38 @@ def test_tree_that_could_overflow_the_stack_is_walked_as_a_two_child_tree(monkey
     assert nodes["20"] > 1.5 * nodes[None]          # the two-child tree has about twice the nodes
 
 
+def test_eight_wide_tree_too_deep_for_the_group_stack_is_walked_as_a_two_child_tree(monkeypatch):
+    """Under option bvh_width 8 a ray holds one group per level plus one; a tree deeper than a lane's stack of groups (a
+    degenerate chain; here PTRACE_STACK_LIMIT = 8 against the 70 k-triangle scene's 11) is walked as the two-child tree of
+    the same build, whose records follow the other order.  Same image and hits either way."""
+    s = pa.Scene("blob70k"); sky = pa.procedural_sky(64, 32)
+    W, H = 96, 54
+    p = pa.make_params(s, W, H, seed=0.5, spp=2, max_bounces=6)
+    want, want_ids, _ = po.Oracle.from_scene(s, sky, accel=True).render(p, W, H, threads=8)
+    nodes = {}
+    for limit in (None, "8"):
+        if limit:
+            monkeypatch.setenv("PTRACE_STACK_LIMIT", limit)
+        t = pa.PathTracer(0)
+        try:
+            t.set_option("bvh_width", 8)
+            t.load_scene(s, sky); t.resize(W, H); t.render(p)
+            assert _same(t.read_result(), want) and (t.read_hit_ids() == want_ids).all()
+            rng = np.random.default_rng(5)
+            od = np.zeros((3000, 6), np.float32); od[:, :3] = rng.uniform(-4, 4, (3000, 3)); od[:, 1] = np.abs(od[:, 1]) + 3
+            d = rng.normal(0, 1, (3000, 3)); d[:, 1] = -np.abs(d[:, 1]); od[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+            ib, tb = t.trace_rays(od); ie, te = t.trace_rays(od, brute_force=True)
+            assert (ib == ie).all() and (tb.view(np.uint32) == te.view(np.uint32)).all()
+            nodes[limit] = t.stats()["bvh_nodes"]
+            # and the other widths from the same context: the records change their order with the option
+            for width in (4, 8):
+                t.set_option("bvh_width", width); t.render(p)
+                assert _same(t.read_result(), want) and (t.read_hit_ids() == want_ids).all(), width
+        finally:
+            t.close()
+    assert nodes["8"] > 2.5 * nodes[None]           # one primitive per leaf: a two-child tree of 70 k nodes against 23 k eight-wide ones
+
+
 @pytest.mark.parametrize("left", [1, 0])
 def test_master_mirror_stereo_branch(left):
     """The stereo branch of SetShaderParameters (RayTracingMaster.cs:459-485) through the C++ mirror, one master per eye
@@ -310,7 +342,7 @@ def test_new_targets_are_zero_before_the_next_frame_reads_them():
                 t.write_target(which, sevens)
 
 
-@pytest.mark.parametrize("width", [4, 2])
+@pytest.mark.parametrize("width", [4, 2, 8])
 def test_spheres_seen_from_far_out_on_the_ground_plane(width):
     """tools/soak_params.py 200 20261111, dispatch 153 608: a camera 40 above the ground with a 175 degree field of view
     sees the plane 4 215 units away; a path that bounces there looks back at the spheres from a distance at which

@@ -202,7 +202,8 @@ def test_bvh_builder_invariants_and_stack_bound(tmp_path):
     """tools/bvh_check.cpp (host only, under AddressSanitizer + UBSan): on named scenes and on degenerate inputs every
     primitive sits in exactly one leaf, every dequantised box holds what lies below it, and the builder's worst-case
     traversal-stack figure for the four-wide tree equals an independent walk of the tree - the figure the library uses to
-    decide whether a lane's 92-entry stack can take that tree ("4000 points on a line" needs 126 and must not)."""
+    decide whether a lane's 92-entry stack can take that tree ("4000 points on a line" needs 126 and must not).  The
+    eight-wide layout gets the same checks plus a host restatement of the walk by groups over random rays."""
     import subprocess
     exe = str(tmp_path / "bvh_check")
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-I", "include", "-I", "pathtracing_amd/csrc",
@@ -211,8 +212,12 @@ def test_bvh_builder_invariants_and_stack_bound(tmp_path):
     subprocess.run(cmd, cwd=ROOT, check=True)
     out = subprocess.run([exe], cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0 and "bvh_check ok" in out.stdout, out.stdout + out.stderr
-    need = {ln.split("  ")[0].strip(): int(ln.split("stack need")[1].split("/")[1].split(",")[0]) for ln in out.stdout.splitlines() if "stack need" in ln}
+    need = {ln.split("  ")[0].strip(): int(ln.split("stack need")[1].split("/")[1].split(",")[0]) for ln in out.stdout.splitlines()
+            if "stack need" in ln and "eight-wide" not in ln}
     assert need["4000 points on a line"] > 92 and need["hall260k leaf 2"] < 60
+    # the eight-wide tree: one group per level plus one; the bench scenes stay far below the 46 groups a lane's stack holds
+    need8 = {ln.split("  ")[0].strip(): int(ln.split("stack need")[1].split("(")[0]) for ln in out.stdout.splitlines() if "eight-wide" in ln}
+    assert need8["hall260k leaf 2"] <= 12 and need8["blob70k leaf 2"] <= 12 and need8["4000 points on a line"] <= 46
 
 
 def test_matrix_inverse_and_stereo_eye_matrices():

@@ -28,7 +28,7 @@ def _free_device_memory():
     return free.value
 
 
-@pytest.mark.parametrize("width", [4, 2])
+@pytest.mark.parametrize("width", [4, 2, 8])
 def test_static_ray_query_equals_the_allocating_one(width):
     rng = np.random.default_rng(7 + width)
     t = pa.PathTracer(0)

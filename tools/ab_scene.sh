@@ -3,9 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 ARGS=$1; shift
-cp pathtracing_amd/csrc/libptrace.so /tmp/libptrace_base.so
 for lib in base "$@"; do
-  if [ "$lib" = base ]; then cp /tmp/libptrace_base.so pathtracing_amd/csrc/libptrace.so; else cp pathtracing_amd/csrc/$lib pathtracing_amd/csrc/libptrace.so; fi
+  if [ "$lib" = base ]; then unset PTRACE_LIB; else export PTRACE_LIB=$lib; fi      # loaded through PTRACE_LIB (_ffi.py): the installed library is not touched
   for rep in 1 2; do echo -n "$lib: "; timeout -k 5 90 python -u tools/scene_rate.py $ARGS || exit 1; done
 done
-cp /tmp/libptrace_base.so pathtracing_amd/csrc/libptrace.so

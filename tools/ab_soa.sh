@@ -6,10 +6,9 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 OUT=$REPO/gpurun_out/r2_soa_ab.txt
 : > $OUT
-cp pathtracing_amd/csrc/libptrace.so /tmp/libptrace_base.so
 export TMPDIR=/tmp
 for lib in base soa; do
-  if [ $lib = base ]; then cp /tmp/libptrace_base.so pathtracing_amd/csrc/libptrace.so; else cp pathtracing_amd/csrc/libptrace_soa.so pathtracing_amd/csrc/libptrace.so; fi
+  if [ $lib = base ]; then unset PTRACE_LIB; else export PTRACE_LIB=libptrace_soa.so; fi      # loaded through PTRACE_LIB: the installed library is not touched
   for rep in 1 2; do
     timeout -k 5 120 python -u bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stereo --no-reproj --in-flight 1 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', 'Mrays/s', round(d['value_single_dispatch'],1), 'nodes/ray', round(d['roofline']['nodes_per_ray'],3), 'rays/launch', int(d['config']['rays_per_step']), 'crc', d['image_crc'])" >> $OUT
   done
@@ -17,5 +16,4 @@ for lib in base soa; do
   python3 tools/prof_summary.py gpurun_out/soa_$lib 2>&1 | grep "path_sched" | sed "s/^/$lib /" >> $OUT
   find gpurun_out/soa_$lib -name "*.db" -delete
 done
-cp /tmp/libptrace_base.so pathtracing_amd/csrc/libptrace.so
 cat $OUT

@@ -24,6 +24,138 @@ static bool contains(const float *lo, const float *hi, const Aabb &b)
     return true;
 }
 
+// The eight-wide layout (bvh.hpp, Bvh8Node): every primitive is the record of exactly one leaf slot, the inner children of a
+// node are consecutive from child_base and the records of its leaves from leaf_base (each node and each record referenced
+// once), every dequantised child box contains what lies below it, absent slots hold the inside-out box, and the depth
+// figure is the one an independent walk finds.  Then rays: a host restatement of the device's walk by groups (base, member
+// slots, hits in octant order; one stack entry per visit) must reach every primitive whose own box the ray enters.
+static bool slab_hit(const float o[3], const float inv[3], const float lo[3], const float hi[3])
+{
+    float tn = 0.0f, tf = INFINITY;
+    for (int a = 0; a < 3; a++) {
+        const float t0 = (lo[a] - o[a]) * inv[a], t1 = (hi[a] - o[a]) * inv[a];
+        tn = std::fmax(tn, std::fmin(t0, t1)); tf = std::fmin(tf, std::fmax(t0, t1));
+    }
+    return tn <= tf * 1.000002f;
+}
+static uint32_t octant_order(uint32_t x, uint32_t oct)
+{
+    const uint32_t s1 = oct & 1u, s2 = oct & 2u, s4 = oct & 4u;
+    x = ((x & 0x5555u) << s1) | ((x & 0xaaaau) >> s1);
+    x = ((x & 0x3333u) << s2) | ((x & 0xccccu) >> s2);
+    x = ((x & 0x0f0fu) << s4) | ((x & 0xf0f0u) >> s4);
+    return x;
+}
+static int check8(const char *what, const std::vector<Aabb> &boxes)
+{
+    ptrace::BvhResult r = ptrace::build_bvh(boxes, 2, 0, 1.0f, true);
+    const size_t n = boxes.size();
+    if (n == 0) return r.nodes8.empty() && r.order8.empty() ? 0 : 1;
+    int bad = 0;
+    if (r.order8.size() != n) bad++;
+    std::vector<int> seen(n, 0), rec_ref(n, 0), node_ref(r.nodes8.size(), 0);
+    for (uint32_t id : r.order8) { if (id >= n) bad++; else seen[id]++; }
+    for (int c : seen) if (c != 1) bad++;
+    struct It { uint32_t node; int depth; };
+    std::vector<It> st{{0u, 1}};
+    node_ref[0]++;
+    int depth = 0;
+    std::vector<Aabb> node_box(r.nodes8.size());      // dequantised box of every node's own slot in its parent; the root: its grid
+    while (!st.empty() && !bad) {
+        const It it = st.back(); st.pop_back();
+        depth = std::max(depth, it.depth);
+        const ptrace::Bvh8Node &nd = r.nodes8[it.node];
+        if (nd.imask & nd.lmask) bad++;
+        const float cell[3] = {std::ldexp(1.0f, nd.ex - 127), std::ldexp(1.0f, nd.ey - 127), std::ldexp(1.0f, nd.ez - 127)};
+        uint32_t ni = 0, nl = 0;
+        for (int k = 0; k < 8; k++) {
+            const uint8_t ql[3] = {nd.qlo_x[k], nd.qlo_y[k], nd.qlo_z[k]}, qh[3] = {nd.qhi_x[k], nd.qhi_y[k], nd.qhi_z[k]};
+            const bool inner = (nd.imask >> k) & 1, leaf = (nd.lmask >> k) & 1;
+            if (!inner && !leaf) { for (int a = 0; a < 3; a++) if (ql[a] != 255 || qh[a] != 0) bad++; continue; }
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) { lo[a] = nd.org[a] + ql[a] * cell[a]; hi[a] = nd.org[a] + qh[a] * cell[a]; }
+            if (inner) {
+                const uint32_t c = nd.child_base + ni++;
+                if (c >= r.nodes8.size()) { bad++; continue; }
+                node_ref[c]++;
+                for (int a = 0; a < 3; a++) { node_box[c].lo[a] = lo[a]; node_box[c].hi[a] = hi[a]; }
+                // the child's own grid must lie inside the slot's box: its children are tested against their own planes only
+                const ptrace::Bvh8Node &cn = r.nodes8[c];
+                for (int a = 0; a < 3; a++) if (std::isfinite(cn.org[a]) && !(cn.org[a] >= lo[a])) bad++;
+                st.push_back({c, it.depth + 1});
+            } else {
+                const uint32_t s = nd.leaf_base + nl++;
+                if (s >= n) { bad++; continue; }
+                rec_ref[s]++;
+                if (!contains(lo, hi, boxes[r.order8[s]])) bad++;
+            }
+        }
+    }
+    for (int c : rec_ref) if (c != 1) bad++;
+    for (int c : node_ref) if (c != 1) bad++;
+    if (depth != r.depth8 || r.stack_need8 != depth + 1) bad++;
+    // ---- rays through the tree, by groups
+    std::mt19937 rng(17);
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    Aabb all = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+    for (const Aabb &b : boxes) for (int a = 0; a < 3; a++) if (std::fabs(b.lo[a]) < 1e17f && std::fabs(b.hi[a]) < 1e17f) { all.lo[a] = std::fmin(all.lo[a], b.lo[a]); all.hi[a] = std::fmax(all.hi[a], b.hi[a]); }
+    int missed = 0, max_sp = 0;
+    long visits = 0, tests = 0;
+    const int n_rays = n > 100000 ? 64 : 400;
+    for (int ray = 0; ray < n_rays && !bad; ray++) {
+        float o[3], d[3], inv[3];
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (all.lo[a] + all.hi[a]), h = 0.5f * (all.hi[a] - all.lo[a]) + 1e-3f;
+            o[a] = std::isfinite(c) ? c + 1.5f * h * u(rng) : u(rng);
+            d[a] = u(rng); if (ray % 7 == 0 && a == ray % 3) d[a] = 0.0f;       // axis-parallel ones too
+            inv[a] = 1.0f / (std::fabs(d[a]) < 1e-18f ? std::copysign(1e-18f, d[a]) : d[a]);
+        }
+        const uint32_t oct = (uint32_t)std::signbit(inv[0]) | ((uint32_t)std::signbit(inv[1]) << 1) | ((uint32_t)std::signbit(inv[2]) << 2);
+        std::vector<char> reached(n, 0);
+        struct G { uint32_t base, mask; };
+        std::vector<G> stack;
+        G cur = {0u, 0x80000000u | (1u << 8) | (1u << oct)};
+        auto take = [&](G &g) { const uint32_t p = (uint32_t)__builtin_ctz(g.mask); g.mask &= g.mask - 1u; const uint32_t slot = p ^ oct;
+                                 return g.base + (uint32_t)__builtin_popcount((g.mask >> 8) & 0xffu & ((1u << slot) - 1u)); };
+        while (cur.mask) {
+            if (cur.mask & 0x80000000u) {
+                const uint32_t node = take(cur);
+                if (cur.mask & 0xffu) stack.push_back(cur);
+                visits++;
+                const ptrace::Bvh8Node &nd = r.nodes8[node];
+                const float cell[3] = {std::ldexp(1.0f, nd.ex - 127), std::ldexp(1.0f, nd.ey - 127), std::ldexp(1.0f, nd.ez - 127)};
+                uint32_t hits = 0;
+                for (int k = 0; k < 8; k++) {
+                    const uint8_t ql[3] = {nd.qlo_x[k], nd.qlo_y[k], nd.qlo_z[k]}, qh[3] = {nd.qhi_x[k], nd.qhi_y[k], nd.qhi_z[k]};
+                    float lo[3], hi[3];
+                    for (int a = 0; a < 3; a++) { lo[a] = nd.org[a] + ql[a] * cell[a]; hi[a] = nd.org[a] + qh[a] * cell[a]; }
+                    if (ql[0] <= qh[0] && ql[1] <= qh[1] && ql[2] <= qh[2] && slab_hit(o, inv, lo, hi)) hits |= 1u << k;
+                }
+                const uint32_t ord = octant_order((hits & nd.imask) | ((hits & nd.lmask) << 8), oct), ih = ord & 0xffu, lh = ord >> 8;
+                const G inner = {nd.child_base, 0x80000000u | ((uint32_t)nd.imask << 8) | ih}, leaves = {nd.leaf_base, (nd.lmask << 8) | lh};
+                if (lh) { if (ih) stack.push_back(inner); cur = leaves; }
+                else if (ih) cur = inner;
+                else if (!stack.empty()) { cur = stack.back(); stack.pop_back(); }
+                else cur.mask = 0;
+                max_sp = std::max(max_sp, (int)stack.size());
+            } else {
+                const uint32_t rec = take(cur);
+                if (rec < n) reached[r.order8[rec]]++; else bad++;
+                tests++;
+                if (!(cur.mask & 0xffu)) { if (!stack.empty()) { cur = stack.back(); stack.pop_back(); } else cur.mask = 0; }
+            }
+        }
+        for (size_t i = 0; i < n; i++) {
+            if (reached[i] > 1) bad++;
+            if (!reached[i] && slab_hit(o, inv, boxes[i].lo, boxes[i].hi)) missed++;
+        }
+    }
+    if (missed || max_sp > r.stack_need8) bad++;
+    std::printf("%-28s %8zu prims: %7zu eight-wide nodes, depth %2d, stack need %2d (rays held %2d), %.1f visits and %.1f tests per ray, %s\n", what, n,
+                r.nodes8.size(), r.depth8, r.stack_need8, max_sp, (double)visits / n_rays, (double)tests / n_rays, bad ? "INVALID" : "ok");
+    return bad;
+}
+
 static int check(const char *what, const std::vector<Aabb> &boxes, int leaf)
 {
     ptrace::BvhResult r = ptrace::build_bvh(boxes, leaf, 0, 1.0f);
@@ -65,7 +197,7 @@ static int check(const char *what, const std::vector<Aabb> &boxes, int leaf)
     if (need4 != r.stack_need4 || r.stack_need2 > ptrace::kMaxDepth + 1 || r.stack_need4 > 3 * depth) bad++;
     std::printf("%-28s %8zu prims: %7zu nodes, %7zu wide nodes, depth %2d / %2d, stack need %2d / %3d, %s\n", what, n, r.nodes.size(),
                 r.nodes4.size(), r.depth, depth, r.stack_need2, r.stack_need4, bad ? "INVALID" : "ok");
-    return bad;
+    return bad + check8(what, boxes);
 }
 
 // split_references: every point of a triangle lies in one of the triangle's reference boxes, the number of additional

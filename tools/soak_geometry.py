@@ -93,7 +93,7 @@ def run(budget=60.0, seed=1):
                     vals[int(rng.integers(0, 10))] = rng.choice(special)
                 ent.append((tuple(vals[0:3]), float(vals[3]), tuple(vals[4:7]), int(rng.choice([pa.PT_LOBE_PHONG, pa.PT_LOBE_GGX])), tuple(3 * vals[7:10])))
             mats = pa.materials(ent)
-        width = int(rng.choice([2, 4]))
+        width = int(rng.choice([2, 4, 8]))
         t.set_option("bvh_width", width)
         t.set_option("split_percent", int(rng.choice([0, 30, 30, 400])))
         t.set_option("instancing", int(rng.random() < 0.6))

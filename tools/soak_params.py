@@ -33,7 +33,7 @@ def run(budget=60.0, seed=1):
     while time.time() - t0 < budget:
         name = str(rng.choice(list(scenes))); s = scenes[name]; o = oracles[name]
         W = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 33, 64, 65, int(rng.integers(1, 90))])); H = int(rng.choice([1, 2, 5, 8, 17, 36, int(rng.integers(1, 70))]))
-        width = int(rng.choice([2, 4])); reuse = int(rng.random() < 0.2)
+        width = int(rng.choice([2, 4, 8])); reuse = int(rng.random() < 0.2)
         t.set_option("bvh_width", width)
         t.set_option("reuse_primary_hit", reuse)
         if current != name:

@@ -30,7 +30,7 @@ def run(budget=60.0, seed=1):
         mode = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12]))
         spp = 1 if mode >= 10 else int(rng.integers(1, 4)); maxb = int(rng.integers(1, 7)); n = int(rng.integers(3, 7))
         step = tuple(float(x) for x in rng.uniform(-0.3, 0.3, 3))
-        t.set_option("bvh_width", int(rng.choice([2, 4])))
+        t.set_option("bvh_width", int(rng.choice([2, 4, 8])))
         t.load_scene(s, sky); t.resize(W, H)
         desc = f"{name} {W}x{H} mode {mode} spp {spp} bounces {maxb} frames {n} step {step}"
         if mode in (5, 6, 7, 8):

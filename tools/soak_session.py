@@ -36,7 +36,7 @@ def diagnose(t, p, old, before, gpu, model, name, objs, W, H, frames):
         print("  again,", label, ": equals the first GPU frame", eq_first, ", equals the model", eq_model, flush=True)
 
     again("unchanged")
-    for key, val, label in (("bvh_width", 2, "two-child tree"), ("bvh_width", 4, "four-child tree again"), ("backend", 1, "wavefront stages"),
+    for key, val, label in (("bvh_width", 2, "two-child tree"), ("bvh_width", 8, "eight-child tree"), ("bvh_width", 4, "four-child tree again"), ("backend", 1, "wavefront stages"),
                             ("backend", 2, "ray pool"), ("backend", 0, "scheduled kernel again")):
         try:
             t.set_option(key, val)
