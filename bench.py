@@ -482,6 +482,10 @@ def main():
             out["blob70k_1080p"] = secondary_scene_rate(pa, torch, sky)
             out["ggx_1080p"] = secondary_scene_rate(pa, torch, sky, name=args.scene, ggx=True)
             out["reuse_primary_hit"] = secondary_scene_rate(pa, torch, sky, name=args.scene, reuse=True)
+            # what bit-exactness costs: the same workload with Shade() on the hardware's approximate transcendentals
+            # (same primary hits and random numbers, image within a relative RMSE of 5e-3: tests/test_gpu_fast_intrinsics.py)
+            out["fast_intrinsics"] = secondary_scene_rate(pa, torch, sky, name=args.scene, fast=True)
+            out["value_fast_intrinsics"] = out["fast_intrinsics"]["value"]
             # 41 % of the headline's rays repeat a pixel's camera ray (the shader applies no jitter); this is the rate of
             # the rays that differ, i.e. of incoherent traversal
             out["value_distinct_rays"] = out["reuse_primary_hit"]["value"]
@@ -718,13 +722,15 @@ def stereo_frame_time(pa, torch, frames=30):
                       "blocks_per_cu 2 each (the two dispatches overlap)"}
 
 
-def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False):
+def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False, fast=False):
     """Mrays/s on another scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU): the ~70 k-triangle
     mesh, or (ggx) the bench scene with every mesh object given a GGX metal surface instead of the shader's
     hard-coded Phong one (PtMaterial, an extension)."""
     scene = pa.Scene(name)
     t = pa.PathTracer(torch.cuda.current_device())
     t.load_scene(scene, sky); t.resize(1920, 1080)
+    if fast:
+        t.set_option("fast_intrinsics", 1)
     if reuse:   # option: a pixel's camera ray (the same for all its samples: the shader has no jitter) is traced once
         t.set_option("reuse_primary_hit", 1)
     if ggx:
@@ -740,7 +746,8 @@ def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, re
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
             "config": f"{name} ({scene.n_triangles} triangles + spheres + plane{', GGX copper on every mesh' if ggx else ''}), "
                       "1920x1080, 8 bounces, 16 spp, 1 GPU, one dispatch at a time"
-                      + (", option reuse_primary_hit: value counts only the rays actually traced (same image)" if reuse else "")}
+                      + (", option reuse_primary_hit: value counts only the rays actually traced (same image)" if reuse else "")
+                      + (", option fast_intrinsics: approximate hardware transcendentals in Shade(), not bit-exact" if fast else "")}
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):

@@ -175,9 +175,11 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                PtStats.rays then counts only the rays actually traced.
  *   "refit"      1 (default): pt_update_transforms refits the four-wide tree on the device; 0: it rebuilds on the host.
  *   "instancing"  0 (default): every mesh object is flattened into world-space triangle records.  1: mesh objects with the
- *                same index range (what objects sharing a sharedMesh get from RebuildMeshObjectBuffers,
- *                RayTracingMaster.cs:387-408) whose localToWorld is rotation or mirror x uniform scale + translation
- *                share ONE tree over the mesh's object-space triangles, under a top-level tree with a box per
+ *                same object-space triangles - RebuildMeshObjectBuffers (RayTracingMaster.cs:387-408) gives every object
+ *                its own copy of its mesh's vertices and indices, so objects sharing a sharedMesh are recognised by the
+ *                content of their ranges (equal indices relative to the range's smallest, bit-identical positions), as
+ *                are objects handed one common range - whose localToWorld is rotation or mirror x uniform scale +
+ *                translation share ONE tree over the mesh's object-space triangles, under a top-level tree with a box per
  *                object; sheared or unevenly scaled objects, meshes used once and meshes under 64 triangles stay
  *                flattened.  Triangle tests still run on world-space vertices transformed as the shader transforms
  *                them, so the image does not change.  Host build time and device memory fall with the number of
@@ -337,11 +339,18 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays,
  * every GPU the library runs on holds it until the process ends.  Limits: n_rays <= PT_TRACE_RAYS_STATIC_MAX
  * (PT_ERR_INVALID beyond); the scene must have been built by an earlier pt_render or pt_trace_rays and not changed
  * since, and no ray may start farther from it than that build allowed for (PT_ERR_INVALID says which; the remedy is
- * one ordinary pt_trace_rays call, which rebuilds).  All contexts on a GPU share the array: calls that overlap on one
- * GPU - from different contexts or threads - race; calls on different GPUs do not. */
+ * one ordinary pt_trace_rays call, which rebuilds).  All contexts on a GPU share the array, so calls on one GPU - from
+ * different contexts or threads - must not overlap: a call that finds the array in use returns PT_ERR_INVALID ("in
+ * use") instead of overwriting the other call's rays; calls on different GPUs do not meet. */
 #define PT_TRACE_RAYS_STATIC_MAX 32768
 int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
                          int brute_force, int32_t *ids_out, float *t_out);
+
+/* Test and debugging aid, no counterpart in the reference: how many device or pinned-host allocation and release calls
+ * (hipMalloc, hipFree, hipHostMalloc, hipHostFree) the library has made in this process so far, all contexts together.
+ * Unchanged across a call means the call allocated nothing - which free-memory figures cannot show when a buffer is
+ * allocated and released inside one call. */
+unsigned long long pt_allocation_calls(void);
 
 const char *pt_version(void);
 

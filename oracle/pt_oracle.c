@@ -28,7 +28,8 @@ typedef struct RayHit {                                          /* SH:126-135 *
 
 typedef struct Tri { f3 v0, v1, v2; int32_t object; } Tri;
 
-typedef struct ONode { float lo[3], hi[3]; int32_t left, right; int32_t first, count; } ONode;
+/* thin, len: the largest L^2 / |e1 x e2| and the longest edge L among the triangles below the node (see box_hit) */
+typedef struct ONode { float lo[3], hi[3]; int32_t left, right; int32_t first, count; float thin, len; } ONode;
 
 struct PtoPrepared {
     PtSphere *spheres; int32_t n_spheres;
@@ -179,10 +180,15 @@ static void intersect_tri(const Ray *ray, RayHit *best, const Tri *tr, int32_t i
  * the sign of a difference of squares of the origin's distance D, so it accepts rays passing sqrt(r^2 + k eps D^2) from
  * the centre - units beside a sphere for an origin some 10^4 units out on the ground plane - which is why the spheres
  * (at most a few hundred) are not in the tree at all: trace() tests every one of them, as the shader does.  Moeller-
- * Trumbore's barycentrics err by about 8 eps (L^2 / |e1 x e2|) max(L, D) in world units; `margin`, a distance the
- * boxes are widened by for one ray, grows with the ray's distance from the scene to cover that. */
-static int box_hit(const ONode *n, const Ray *ray, f3 inv, float best, float margin)
+ * Trumbore's barycentrics err by about 8 eps (L^2 / |e1 x e2|) max(L, D) in world units - a sliver ten units long and
+ * a thousandth wide reports hits three units beyond its end from 2 10^4 units away - so every box is widened, for one
+ * ray at distance `far` from the scene, by that expression for the thinnest and the longest triangle below it, and by
+ * `margin` (sixteen times a well-shaped triangle's reach at that distance) at least. */
+static int box_hit(const ONode *n, const Ray *ray, f3 inv, float best, float margin, float far)
 {
+    const float own = 8.0f * 5.9604645e-8f * n->thin * fmaxf(n->len, far);
+    if (own > margin) margin = own;
+    if (!(margin < 1e30f)) margin = 1e30f;        /* a triangle without area below: always entered */
     float tx0 = (n->lo[0] - margin - ray->origin.x) * inv.x, tx1 = (n->hi[0] + margin - ray->origin.x) * inv.x;
     float ty0 = (n->lo[1] - margin - ray->origin.y) * inv.y, ty1 = (n->hi[1] + margin - ray->origin.y) * inv.y;
     float tz0 = (n->lo[2] - margin - ray->origin.z) * inv.z, tz1 = (n->hi[2] + margin - ray->origin.z) * inv.z;
@@ -206,13 +212,14 @@ static void trace_bvh(const PtoPrepared *p, const Ray *ray, RayHit *best, Counte
     const float fx = fmaxf(fabsf(ray->origin.x - root->lo[0]), fabsf(ray->origin.x - root->hi[0]));
     const float fy = fmaxf(fabsf(ray->origin.y - root->lo[1]), fabsf(ray->origin.y - root->hi[1]));
     const float fz = fmaxf(fabsf(ray->origin.z - root->lo[2]), fabsf(ray->origin.z - root->hi[2]));
-    float margin = 6.4e-6f * sqrtf(fx * fx + fy * fy + fz * fz);
+    const float far = sqrtf(fx * fx + fy * fy + fz * fz);
+    float margin = 6.4e-6f * far;
     if (!(margin < 1e30f)) margin = 1e30f;        /* NaN or infinite origin: every box is entered */
     int32_t stack[128]; int sp = 0;
     stack[sp++] = 0;
     while (sp) {
         const ONode *n = &p->nodes[stack[--sp]];
-        if (!box_hit(n, ray, inv, best->distance, margin)) continue;
+        if (!box_hit(n, ray, inv, best->distance, margin, far)) continue;
         if (n->count) {
             for (int32_t k = 0; k < n->count; k++) {
                 int32_t id = p->order[n->first + k];
@@ -1163,6 +1170,27 @@ PtoPrepared *pto_prepare(const PtoScene *sc, int accel)
 #pragma omp single
         build_node(p, 0, nt, 1e-5f * diag + 1e-6f, cent, np);
         free(cent);
+        /* thinness and edge length per node, children first (a node's index is smaller than its children's) */
+        for (int32_t n = p->n_nodes - 1; n >= 0; n--) {
+            ONode *nd = &p->nodes[n];
+            nd->thin = 0.0f; nd->len = 0.0f;
+            if (nd->count) {
+                for (int32_t q = 0; q < nd->count; q++) {
+                    const Tri *tr = &p->tris[p->order[nd->first + q] - 1 - p->n_spheres];
+                    const f3 e1 = pt_sub3(tr->v1, tr->v0), e2 = pt_sub3(tr->v2, tr->v0), e3 = pt_sub3(e2, e1);
+                    const float l2 = fmaxf(pt_dot3(e1, e1), fmaxf(pt_dot3(e2, e2), pt_dot3(e3, e3)));
+                    const f3 nn = pt_cross3(e1, e2);
+                    float thin = l2 / sqrtf(pt_dot3(nn, nn));
+                    if (!(thin < 1e30f)) thin = 1e30f;              /* no area, NaN */
+                    float len = sqrtf(l2);
+                    if (!(len < 1e30f)) len = 1e30f;
+                    nd->thin = fmaxf(nd->thin, thin); nd->len = fmaxf(nd->len, len);
+                }
+            } else {
+                nd->thin = fmaxf(p->nodes[nd->left].thin, p->nodes[nd->right].thin);
+                nd->len = fmaxf(p->nodes[nd->left].len, p->nodes[nd->right].len);
+            }
+        }
     }
     return p;
 }

@@ -83,6 +83,7 @@ PTRACE_SYMBOLS = {
     "pt_get_stats": (C.c_int, [_ctx, _P(PtStats)]),
     "pt_trace_rays": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pt_trace_rays_static": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pt_allocation_calls": (C.c_ulonglong, []),
     "pt_version": (C.c_char_p, []),
     "pt_group_create": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_void_p)]),
     "pt_group_destroy": (None, [C.c_void_p]),

@@ -760,6 +760,54 @@ __device__ __forceinline__ void intersect_far_spheres(const SceneDev &sc, f3 o, 
 
 // ------------------------------------------------------------------- shading
 
+// The arithmetic Shade() is written on.  Fm<false>: the intrinsics of include/ptrace_fmath.h - correctly rounded division
+// and square root, software sin / cos / pow / acos / atan2 with fixed algorithms - which the oracle shares, so that
+// images agree bit for bit.  Fm<true> (option "fast_intrinsics"): the hardware's approximate reciprocal, square root,
+// reciprocal square root, exp2, log2 and sine (about 1 ulp each) and short polynomials for acos and atan2.  The random
+// numbers do not go through it (rng_next keeps pt_sin): every roulette decision and every (u1, u2) pair is the same in both,
+// only the directions and weights computed from them differ in their last bits.
+template <bool FAST> struct Fm {
+    static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+    static __device__ __forceinline__ float sqrt(float x) { return pt_sqrt(x); }
+    static __device__ __forceinline__ f3 normalize(f3 a) { return pt_normalize3(a); }
+    static __device__ __forceinline__ float pow(float x, float y) { return pt_pow(x, y); }
+    static __device__ __forceinline__ float sin(float x) { return pt_sin(x); }
+    static __device__ __forceinline__ float cos(float x) { return pt_cos(x); }
+    static __device__ __forceinline__ float acos(float x) { return pt_acos(x); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return pt_atan2(y, x); }
+};
+template <> struct Fm<true> {
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ f3 normalize(f3 a) { return pt_scale3(a, __builtin_amdgcn_rsqf(pt_dot3(a, a))); }
+    // x >= 0: 2^(y log2 x); log2(0) = -inf gives 0 for y > 0 and 1 for y == 0 as pow does
+    static __device__ __forceinline__ float pow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+    // v_sin_f32 / v_cos_f32 take revolutions and are specified for |x| <= 256 of them; callers pass angles of a few turns
+    static __device__ __forceinline__ float sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494f); }
+    static __device__ __forceinline__ float cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494f); }
+    // acos x = sqrt(1 - |x|) * p(|x|), mirrored for x < 0 (Abramowitz & Stegun 4.4.45: absolute error below 7e-5)
+    static __device__ __forceinline__ float acos(float x)
+    {
+        const float a = pt_abs(x) < 1.0f ? pt_abs(x) : 1.0f;
+        const float p = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.0187293f, a, 0.0742610f), a, -0.2121144f), a, 1.5707288f);
+        const float r = __builtin_amdgcn_sqrtf(1.0f - a) * p;
+        return x < 0.0f ? 3.14159265f - r : r;
+    }
+    // atan of the smaller over the larger magnitude by an odd polynomial (absolute error below 2e-5), then the octant
+    static __device__ __forceinline__ float atan2(float y, float x)
+    {
+        const float ax = pt_abs(x), ay = pt_abs(y);
+        const float hi = ax > ay ? ax : ay, lo = ax > ay ? ay : ax;
+        const float z = hi > 0.0f ? lo * __builtin_amdgcn_rcpf(hi) : 0.0f, z2 = z * z;
+        float r = z * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.0117212f, z2, 0.05265332f), z2, -0.11643287f), z2, 0.19354346f) * z2 - 0.33262347f, z2, 0.99997726f);
+        if (ay > ax) r = 1.57079633f - r;
+        if (x < 0.0f) r = 3.14159265f - r;
+        return y < 0.0f ? -r : r;
+    }
+};
+
 struct Rng { float seed; float dotp; };  // _Seed and dot(_Pixel, float2(12.9898, 78.233))  SH:47-52
 
 __device__ __forceinline__ float rng_next(Rng &r)  // SH:50-55
@@ -770,24 +818,29 @@ __device__ __forceinline__ float rng_next(Rng &r)  // SH:50-55
 }
 
 // GetTangentSpace + mul(tangentSpaceDir, basis), SH:291-302, SH:313
+template <bool FAST = false>
 __device__ __forceinline__ f3 tangent_to_world(f3 normal, f3 ts);
 
 // SH:304-314
+template <bool FAST = false>
 __device__ __forceinline__ f3 sample_hemisphere(Rng &rs, f3 normal, float alpha)
 {
-    float cosTheta = pt_pow(rng_next(rs), 1.0f / (alpha + 1.0f));
-    float sinTheta = pt_sqrt(1.0f - cosTheta * cosTheta);
+    typedef Fm<FAST> M;
+    float cosTheta = M::pow(rng_next(rs), M::rcp(alpha + 1.0f));
+    float sinTheta = M::sqrt(FAST ? pt_max(1.0f - cosTheta * cosTheta, 0.0f) : 1.0f - cosTheta * cosTheta);
     float phi = 2 * PT_PI * rng_next(rs);
-    f3 ts = pt_make3(pt_cos(phi) * sinTheta, pt_sin(phi) * sinTheta, cosTheta);
-    return tangent_to_world(normal, ts);
+    f3 ts = pt_make3(M::cos(phi) * sinTheta, M::sin(phi) * sinTheta, cosTheta);
+    return tangent_to_world<FAST>(normal, ts);
 }
 
+template <bool FAST>
 __device__ __forceinline__ f3 tangent_to_world(f3 normal, f3 ts)
 {
+    typedef Fm<FAST> M;
     f3 helper = pt_make3(1, 0, 0);
     if (pt_abs(normal.x) > 0.99f) helper = pt_make3(0, 0, 1);
-    f3 tangent = pt_normalize3(pt_cross3(normal, helper));
-    f3 binormal = pt_normalize3(pt_cross3(normal, tangent));
+    f3 tangent = M::normalize(pt_cross3(normal, helper));
+    f3 binormal = M::normalize(pt_cross3(normal, tangent));
     f3 r;
     r.x = pt_fma(ts.z, normal.x, pt_fma(ts.y, binormal.x, ts.x * tangent.x));
     r.y = pt_fma(ts.z, normal.y, pt_fma(ts.y, binormal.y, ts.x * tangent.y));
@@ -796,11 +849,13 @@ __device__ __forceinline__ f3 tangent_to_world(f3 normal, f3 ts)
 }
 
 // SH:324-332: bilinear, Repeat wrap, texel centres at (i+0.5)/N, lerp(a,b,t) = a + t*(b-a).
+template <bool FAST = false>
 __device__ __forceinline__ f3 sky_sample(const SceneDev &sc, f3 dir)
 {
+    typedef Fm<FAST> M;
     if (!sc.sky) return pt_make3(0, 0, 0);
-    float theta = pt_acos(dir.y) / -PT_PI;
-    float phi = pt_atan2(dir.x, -dir.z) / -PT_PI * 0.5f;
+    float theta = FAST ? M::acos(dir.y) * (-1.0f / PT_PI) : pt_acos(dir.y) / -PT_PI;
+    float phi = FAST ? M::atan2(dir.x, -dir.z) * (-0.5f / PT_PI) : pt_atan2(dir.x, -dir.z) / -PT_PI * 0.5f;
     int W = sc.sky_w, H = sc.sky_h;
     float x = phi * (float)W - 0.5f, y = theta * (float)H - 0.5f;
     float x0f = pt_floor(x), y0f = pt_floor(y);
@@ -827,24 +882,26 @@ __device__ __forceinline__ f3 sky_sample(const SceneDev &sc, f3 dir)
 // mirror image of the incoming one about that half-vector.  Returns the throughput f * cos / pdf =
 // F * G * (v.h) / ((n.v)(n.h)) per channel with Schlick's F (F0 = specular) and Smith's separable G, or zero
 // when the sample leaves the upper hemisphere.
+template <bool FAST = false>
 __device__ __forceinline__ f3 sample_ggx(Rng &rs, f3 normal, f3 specular, float smoothness, f3 &d)
 {
+    typedef Fm<FAST> M;
     const float rough = 1.0f - smoothness;
     const float a = pt_max(rough * rough, 1e-3f), a2 = a * a;
     const float u1 = rng_next(rs);
-    const float cos2 = (1.0f - u1) / (1.0f + (a2 - 1.0f) * u1);
-    const float cosT = pt_sqrt(cos2), sinT = pt_sqrt(1.0f - cos2);
+    const float cos2 = M::div(1.0f - u1, 1.0f + (a2 - 1.0f) * u1);
+    const float cosT = M::sqrt(cos2), sinT = M::sqrt(FAST ? pt_max(1.0f - cos2, 0.0f) : 1.0f - cos2);
     const float phi = 2 * PT_PI * rng_next(rs);
-    const f3 h = tangent_to_world(normal, pt_make3(pt_cos(phi) * sinT, pt_sin(phi) * sinT, cosT));
+    const f3 h = tangent_to_world<FAST>(normal, pt_make3(M::cos(phi) * sinT, M::sin(phi) * sinT, cosT));
     const f3 v = pt_make3(-d.x, -d.y, -d.z);
     const float vh = pt_dot3(v, h);
     d = pt_reflect3(d, h);
     const float nl = pt_dot3(normal, d), nv = pt_dot3(normal, v), nh = pt_dot3(normal, h);
     if (!(nl > 0.0f && nv > 0.0f && vh > 0.0f && nh > 0.0f)) return pt_make3(0, 0, 0);
     const float m = 1.0f - vh, m2 = m * m, m5 = m2 * m2 * m;
-    const float g1v = 2.0f * nv / (nv + pt_sqrt(a2 + (1.0f - a2) * nv * nv));
-    const float g1l = 2.0f * nl / (nl + pt_sqrt(a2 + (1.0f - a2) * nl * nl));
-    const float w = g1v * g1l * vh / (nv * nh);
+    const float g1v = M::div(2.0f * nv, nv + M::sqrt(a2 + (1.0f - a2) * nv * nv));
+    const float g1l = M::div(2.0f * nl, nl + M::sqrt(a2 + (1.0f - a2) * nl * nl));
+    const float w = M::div(g1v * g1l * vh, nv * nh);
     return pt_make3((specular.x + (1.0f - specular.x) * m5) * w, (specular.y + (1.0f - specular.y) * m5) * w,
                     (specular.z + (1.0f - specular.z) * m5) * w);
 }
@@ -855,10 +912,11 @@ __device__ __forceinline__ f3 sample_ggx(Rng &rs, f3 normal, f3 specular, float 
 // as the arithmetic allows (emission right after the material fetch, the material folded into one
 // weight before the hemisphere sampling) to keep few registers live across the sampling code.
 // MAT: mesh objects carry their own PtMaterial (SceneDev::mesh_mat), possibly with the GGX lobe.
-template <bool MAT = false, bool INST = false>
+template <bool MAT = false, bool INST = false, bool FAST = false>
 __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d, f3 &energy, f3 &result, float fspp,
                                       float t, int32_t id, uint32_t rec, f3 &hit_pos)
 {
+    typedef Fm<FAST> M;
     int lobe = PT_LOBE_PHONG;
     // What Shade() returns - the hit's emission, or the sky after a miss (SH:371-372) - is added once for all cases
     // below: result += energy * value / spp (SH:866/870) is three correctly rounded divisions, and a wave with mixed
@@ -868,7 +926,7 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
     f3 emitted, position = pt_make3(0, 0, 0), nraw = pt_make3(0, 1, 0), albedo = pt_make3(0, 0, 0), specular = pt_make3(0, 0, 0);
     float smoothness = 0.0f;
     if (!hit) {
-        emitted = sky_sample(sc, d);
+        emitted = sky_sample<FAST>(sc, d);
     } else {
         position = pt_along3(o, t, d);
         if (id == 0) {                                  // SH:162-166
@@ -909,10 +967,10 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
         }
     }
     hit_pos = position;
-    if ((__float_as_uint(fspp) & 0x007fffffu) == 0u) {
+    if (FAST || (__float_as_uint(fspp) & 0x007fffffu) == 0u) {
         // a power of two (wave-uniform): x / 2^k and x * 2^-k are the same correctly rounded number, and the product
         // costs one instruction where the division costs eleven
-        const float inv = 1.0f / fspp;
+        const float inv = M::rcp(fspp);
         result.x += energy.x * emitted.x * inv;
         result.y += energy.y * emitted.y * inv;
         result.z += energy.z * emitted.z * inv;
@@ -925,7 +983,7 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
         energy = pt_make3(0, 0, 0);
         return;
     }
-    const f3 normal = pt_normalize3(nraw);
+    const f3 normal = M::normalize(nraw);
     albedo = pt_make3(pt_min(1.0f - specular.x, albedo.x), pt_min(1.0f - specular.y, albedo.y),
                       pt_min(1.0f - specular.z, albedo.z));
     const float third = 1.0f / 3.0f;
@@ -937,27 +995,27 @@ __device__ __forceinline__ void shade(const SceneDev &sc, Rng &rs, f3 &o, f3 &d,
     const bool spec = roulette < specChance;
     const bool diff = !spec && diffChance > 0 && roulette < specChance + diffChance;
     if (MAT && spec && lobe == PT_LOBE_GGX) {
-        const float k = 1.0f / specChance;
+        const float k = M::rcp(specChance);
         o = pt_along3(position, 0.001f, normal);
-        const f3 w = sample_ggx(rs, normal, specular, smoothness, d);
+        const f3 w = sample_ggx<FAST>(rs, normal, specular, smoothness, d);
         energy.x *= k * w.x;
         energy.y *= k * w.y;
         energy.z *= k * w.z;
     } else if (spec || diff) {
         // (1/chance) * colour, the left factor of SH:352 / SH:359
-        const float k = 1.0f / (spec ? specChance : diffChance);
+        const float k = M::rcp(spec ? specChance : diffChance);
         const f3 weight = spec ? pt_make3(k * specular.x, k * specular.y, k * specular.z)
                                : pt_make3(k * albedo.x, k * albedo.y, k * albedo.z);
         o = pt_along3(position, 0.001f, normal);
         float alpha = 1.0f;
         f3 axis = normal;
         if (spec) {
-            alpha = pt_pow(1000.0f, smoothness * smoothness);
+            alpha = M::pow(1000.0f, smoothness * smoothness);
             axis = pt_reflect3(d, normal);
         }
-        d = sample_hemisphere(rs, axis, alpha);
+        d = sample_hemisphere<FAST>(rs, axis, alpha);
         if (spec) {
-            float f = (alpha + 2) / (alpha + 1);
+            float f = M::div(alpha + 2, alpha + 1);
             float sd = pt_saturate(pt_dot3(normal, d) * f);
             energy.x *= weight.x * sd;
             energy.y *= weight.y * sd;
@@ -1288,7 +1346,7 @@ __device__ __forceinline__ bool is_leaf_ref(int32_t node) { return node < 0 && n
 //   ls0 = (energy.xyz, _Seed)   ls1 = (result.xyz, t of the primary hit)
 //   ls2 = (pixel x | y << 16, sample | bounce << 20, primary record, primary id)   ls3 = (rays, nodes, prims, paths) counters
 //   (sample: below 2^19; in a pixel's first sample kFirstSample | cost of the pixel so far)
-template <int WIDE, bool MAT, bool INST = false>
+template <int WIDE, bool MAT, bool INST = false, bool FAST = false>
 __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
 {
 #if PT_STACK_T
@@ -1420,7 +1478,7 @@ __device__ __forceinline__ void path_sched_body(const RenderArgs &a)
                         }
                     }
                     if (!from_history) {
-                    shade<MAT, INST>(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
+                    shade<MAT, INST, FAST>(sc, rs, o, d, energy, result, (float)a.spp, tbest, idbest, recbest, hit_pos);
                     bool path_done;
                     if (bounce == 0) {
                         primary_id = idbest;
@@ -1650,10 +1708,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_INST_
 // Five waves per SIMD (96 VGPRs): the few values that do not fit are kernel constants spilled once at entry and read back
 // in the shade phase; the node and leaf loops hold no scratch access.  Measured against four waves (128 VGPRs, nothing
 // spilled): +2.5 % rays/s one dispatch at a time, +6 % with three in flight; six waves (80 VGPRs) lose.
+#ifndef PT_SCHED_WAVES
+#define PT_SCHED_WAVES 5   // measurement builds: 4 = 128 VGPRs, nothing spilled inside the loop
+#endif
 template <int WIDE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void path_sched_kernel(const RenderArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SCHED_WAVES))) void path_sched_kernel(const RenderArgs a)
 {
     path_sched_body<WIDE, false>(a);
+}
+
+// Option "fast_intrinsics": the default kernel with Shade() on the hardware's approximate transcendental instructions
+// (Fm<true>); not bit-identical to the oracle - same primary hits, same random numbers, an image within a stated RMSE.
+template <int WIDE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void path_sched_fast_kernel(const RenderArgs a)
+{
+    path_sched_body<WIDE, false, false, true>(a);
 }
 
 // The same kernel for scenes whose mesh objects carry materials (pt_set_mesh_materials); kept apart so that

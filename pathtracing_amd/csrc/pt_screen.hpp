@@ -10,7 +10,13 @@
 //
 // Both kernels stream: per pixel the filter reads 25 history texels that lie within +-8 pixels of it
 // (served by L1/L2: algorithmic traffic is one 16-byte read and one 16-byte write per pixel) and the
-// resolve reads 4 history texels, 4 filtered texels and writes one (48 bytes per pixel).
+// resolve reads 4 history texels, 4 filtered texels and writes one (48 bytes per pixel).  Neither is
+// bound by those bytes: the filter is about 1 300 vector instructions per pixel (25 software exp, 25
+// bounds-checked taps), the resolve 700.  Two rearrangements of the memory side were built, found bit-
+// identical and measured at 1920x1080 against 58 and 41 microseconds for the kernels below: each
+// workgroup's neighbourhood copied into LDS first and the taps read from there (7 and 4 sixteen-byte
+// loads per lane instead of 26 and 13): 82 and 51; every tap's load made unconditional (texel 0
+// stands in outside the image, selected away afterwards) so that none sits behind a branch: 66 and 41.
 #pragma once
 
 #include "pt_device.hpp"

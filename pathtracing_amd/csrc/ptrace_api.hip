@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -22,6 +23,17 @@
 #include "pt_refit.hpp"
 
 using namespace ptrace;
+
+// Every device or pinned-host allocation and release the library makes goes through these four, which count the calls
+// (pt_allocation_calls): a test can then see that an entry point which promises to allocate nothing made none - free
+// memory before and after would not show a hipMalloc that was followed by its hipFree.
+namespace {
+std::atomic<unsigned long long> g_allocation_calls{0};
+inline hipError_t dev_malloc(void **p, size_t bytes) { g_allocation_calls++; return hipMalloc(p, bytes); }
+inline hipError_t dev_free(void *p) { g_allocation_calls++; return hipFree(p); }
+inline hipError_t host_malloc(void **p, size_t bytes, unsigned flags) { g_allocation_calls++; return hipHostMalloc(p, bytes, flags); }
+inline hipError_t host_free(void *p) { g_allocation_calls++; return hipHostFree(p); }
+}  // namespace
 
 // The tree over one shared mesh's object-space triangles (two-level scenes), kept between builds: moving instances
 // then costs the top-level tree only.  Valid while the geometry is the one of the last pt_set_meshes and the padding it was
@@ -139,6 +151,8 @@ struct pt_context {
     int sched8_blocks_per_cu = 0, sched8_ext_blocks_per_cu = 0; // and of the two kernels' eight-wide instantiations
     int blocks_per_cu = 0;                 // option "blocks_per_cu": 0 = as many as fit
     int reuse_primary = 0;                 // option "reuse_primary_hit"
+    int fast_intrinsics = 0;               // option "fast_intrinsics": Shade() on the hardware's approximate rcp / rsq / sqrt / exp2 / log2 / sin (plain path tracing only)
+    int sched_fast_blocks_per_cu = 0, sched8_fast_blocks_per_cu = 0;
     int backend = 0;                       // 0 = path_sched_kernel (one ray per lane), 1 = wavefront stages, 2 = path_pool_kernel (ray pool per wave)
     int pool_blocks_per_cu = 0, pool_ext_blocks_per_cu = 0;   // resident one-wave blocks per CU of path_pool_kernel / path_pool_mat_kernel
     int pool_vote_shade = 56, pool_vote_node = 56, pool_vote_leaf = 32, pool_cont = 48;
@@ -201,6 +215,18 @@ namespace {
 constexpr int kMaxScratchDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned char *g_scratch_ptr[kMaxScratchDevices] = {};
+// 1 while a pt_trace_rays_static call is between its first copy into the device's array and its last copy out of it:
+// a second call on the same GPU - another context, another thread - is refused instead of overwriting the first one's rays
+std::atomic<int> g_scratch_busy[kMaxScratchDevices] = {};
+struct ScratchLease {
+    int device; bool held;
+    explicit ScratchLease(int dev) : device(dev), held(false)
+    {
+        int expected = 0;
+        held = g_scratch_busy[dev].compare_exchange_strong(expected, 1);
+    }
+    ~ScratchLease() { if (held) g_scratch_busy[device].store(0); }
+};
 
 // Call with `device` current.
 hipError_t resolve_scratch(int device)
@@ -265,7 +291,7 @@ struct DeviceGuard {
 template <class T>
 void free_dev(T *&p)
 {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { (void)dev_free(p); p = nullptr; }
 }
 
 // Host to device on the context's stream, complete on return.  (hipMemcpy and hipMemset work on the null stream, which the
@@ -283,7 +309,7 @@ int upload(pt_context *ctx, T *&dst, const void *src, size_t bytes)
 {
     free_dev(dst);
     if (bytes == 0) return PT_OK;
-    PT_HIP(ctx, hipMalloc((void **)&dst, bytes));
+    PT_HIP(ctx, dev_malloc((void **)&dst, bytes));
     return h2d(ctx, dst, src, bytes);
 }
 
@@ -293,8 +319,12 @@ static inline void box_reset_inf(Aabb &b)
 }
 
 // ---- two-level scenes ----------------------------------------------------------------------------------------------
-// Mesh objects with the same index range are instances of one mesh (that is how RebuildMeshObjectBuffers lays out objects
-// that share a sharedMesh, RayTracingMaster.cs:387-408).  A group of two or more of them gets one tree over the mesh's
+// Mesh objects with the same object-space triangles are instances of one mesh.  RebuildMeshObjectBuffers appends a COPY of
+// mesh.vertices and of the indices, offset by the copy's first vertex, for every object (RayTracingMaster.cs:387-408), so
+// objects sharing a sharedMesh arrive with different index ranges and different vertex ranges of equal content: they are
+// recognised by that content - equal index counts, indices equal after subtracting each range's smallest index, and
+// bit-identical positions at the referenced vertices (a hash, then a full comparison) - and hosts that keep one copy and
+// hand every object the same range are covered by the same rule.  A group of two or more gets one tree over the mesh's
 // object-space triangles if every member is placed by a similarity: localToWorld = rotation (or mirror) * uniform
 // scale + translation, finite, scale within [1e-3, 1e3].  Under a similarity a box padded by p in object space holds
 // everything within p * scale of the triangle in world space, whichever way the object is turned; shears and uneven
@@ -343,14 +373,55 @@ void affine_inverse_rows(const float *m, double inv[3][4])
     }
 }
 
-std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, std::vector<int> &obj_group)
+// An index range as a mesh: its smallest index, and a hash of the indices relative to it together with the positions they name.
+struct RangeContent { int32_t offset, count, base; uint64_t hash; };
+RangeContent range_content(int32_t offset, int32_t count, const std::vector<int32_t> &indices, const std::vector<float> &vertices)
+{
+    RangeContent rc = {offset, count, 0, 1469598103934665603ull};
+    int32_t base = std::numeric_limits<int32_t>::max();
+    for (int32_t i = offset; i < offset + count; i++) base = std::min(base, indices[(size_t)i]);
+    rc.base = count ? base : 0;
+    for (int32_t i = offset; i < offset + count; i++) {
+        uint32_t w[4];
+        w[0] = (uint32_t)(indices[(size_t)i] - rc.base);
+        std::memcpy(&w[1], &vertices[3 * (size_t)indices[(size_t)i]], 12);
+        for (uint32_t x : w) { rc.hash ^= x; rc.hash *= 1099511628211ull; rc.hash ^= rc.hash >> 29; }
+    }
+    return rc;
+}
+bool same_content(const RangeContent &a, const RangeContent &b, const std::vector<int32_t> &indices, const std::vector<float> &vertices)
+{
+    if (a.count != b.count || a.hash != b.hash) return false;
+    for (int32_t i = 0; i < a.count; i++) {
+        const int32_t ia = indices[(size_t)(a.offset + i)], ib = indices[(size_t)(b.offset + i)];
+        if (ia - a.base != ib - b.base || std::memcmp(&vertices[3 * (size_t)ia], &vertices[3 * (size_t)ib], 12) != 0) return false;
+    }
+    return true;
+}
+
+std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, const std::vector<int32_t> &indices, const std::vector<float> &vertices,
+                                      std::vector<int> &obj_group)
 {
     std::vector<MeshGroup> groups;
     int min_tris = kMinInstanceTris;
     if (const char *env = std::getenv("PTRACE_INSTANCE_MIN_TRIS")) min_tris = std::max(1, std::atoi(env));
-    std::vector<std::pair<std::pair<int32_t, int32_t>, int>> keyed;      // ((offset, count), object)
+    // every distinct index range is read once; ranges of equal content then share a class, named by its first range
+    std::vector<std::pair<std::pair<int32_t, int32_t>, int>> by_range;   // ((offset, count), object)
     for (size_t o = 0; o < objects.size(); o++)
-        if (objects[o].indices_count / 3 >= min_tris && objects[o].indices_offset >= 0) keyed.push_back({{objects[o].indices_offset, objects[o].indices_count}, (int)o});
+        if (objects[o].indices_count / 3 >= min_tris && objects[o].indices_offset >= 0) by_range.push_back({{objects[o].indices_offset, objects[o].indices_count}, (int)o});
+    std::sort(by_range.begin(), by_range.end());
+    std::vector<RangeContent> classes;
+    std::vector<std::pair<std::pair<int32_t, int32_t>, int>> keyed;      // ((offset, count) of the object's class, object)
+    for (size_t i = 0; i < by_range.size();) {
+        const RangeContent rc = range_content(by_range[i].first.first, by_range[i].first.second, indices, vertices);
+        size_t cls = 0;
+        while (cls < classes.size() && !same_content(classes[cls], rc, indices, vertices)) cls++;
+        if (cls == classes.size()) classes.push_back(rc);
+        size_t j = i;
+        for (; j < by_range.size() && by_range[j].first == by_range[i].first; j++)
+            keyed.push_back({{classes[cls].offset, classes[cls].count}, by_range[j].second});
+        i = j;
+    }
     std::sort(keyed.begin(), keyed.end());
     for (size_t i = 0; i < keyed.size();) {
         size_t j = i;
@@ -399,7 +470,7 @@ int rebuild_scene(pt_context *ctx)
     std::vector<int> obj_group(ctx->objects.size(), -1);
     std::vector<MeshGroup> groups;
 #ifndef PT_NODES_SOA
-    if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, obj_group);
+    if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, ctx->indices, ctx->vertices, obj_group);
 #endif
     ctx->flatten_once = false;
     std::vector<Aabb> group_bounds(groups.size()); std::vector<char> group_bounds_done(groups.size(), 0);
@@ -829,8 +900,8 @@ int rebuild_scene(pt_context *ctx)
         if ((rc = upload(ctx, ctx->d_build_matrices, slot_clip.empty() ? nullptr : mats.data(), slot_clip.empty() ? 0 : mats.size() * sizeof(float)))) return rc;
         if ((rc = upload(ctx, ctx->d_level_nodes, level_nodes.data(), level_nodes.size() * sizeof(int32_t)))) return rc;
         free_dev(ctx->d_prim_box); free_dev(ctx->d_node_box);
-        PT_HIP(ctx, hipMalloc((void **)&ctx->d_prim_box, nR * 6 * sizeof(float)));
-        PT_HIP(ctx, hipMalloc((void **)&ctx->d_node_box, nN * 6 * sizeof(float)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_prim_box, nR * 6 * sizeof(float)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_node_box, nN * 6 * sizeof(float)));
         ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
         ctx->refit_ready = !ctx->objects.empty();
     }
@@ -906,7 +977,10 @@ int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
             int rc = rebuild_scene(ctx);
             if (rc) return rc;
         }
-        if (ctx->spheres.empty() && ctx->n_inst == 0) break;      // only sphere boxes and instanced meshes' boxes are padded by the reach
+        // every box is padded for ray origins within the reach: the spheres' by the slack of IntersectSphere's difference of
+        // squares, the triangles' by their own fuzz (triangle_fuzz: a sliver seen from 2 10^4 units away reports hits units
+        // beyond its end), the instanced meshes' by the rounding of the ray's transform
+        if (ctx->n_prims == 0) break;
         const float need = reach_needed(ctx, origins, n, stride);
         if (!(need > ctx->sphere_reach)) break;
         ctx->sphere_reach_request = 2.0f * need;
@@ -954,7 +1028,7 @@ int ensure_stack_overflow(pt_context *ctx, size_t threads)
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_dev(ctx->d_stack_ovf);
     ctx->stack_ovf_threads = 0;
-    PT_HIP(ctx, hipMalloc((void **)&ctx->d_stack_ovf, threads * kStackOverflow * sizeof(uint32_t)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_stack_ovf, threads * kStackOverflow * sizeof(uint32_t)));
     ctx->stack_ovf_threads = threads;
     return PT_OK;
 }
@@ -965,15 +1039,15 @@ int ensure_wavefront_state(pt_context *ctx, size_t slots, size_t iters)
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         free_dev(ctx->wf_state); free_dev(ctx->wf_queues);
         ctx->wf_slots = 0;
-        PT_HIP(ctx, hipMalloc((void **)&ctx->wf_state, slots * 5 * sizeof(float4)));
-        PT_HIP(ctx, hipMalloc((void **)&ctx->wf_queues, slots * 2 * sizeof(uint32_t)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->wf_state, slots * 5 * sizeof(float4)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->wf_queues, slots * 2 * sizeof(uint32_t)));
         ctx->wf_slots = slots;
     }
     if (iters > ctx->wf_iters) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         free_dev(ctx->wf_counters);
         ctx->wf_iters = 0;
-        PT_HIP(ctx, hipMalloc((void **)&ctx->wf_counters, (iters + 2) * 2 * sizeof(uint32_t)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->wf_counters, (iters + 2) * 2 * sizeof(uint32_t)));
         ctx->wf_iters = iters;
     }
     return PT_OK;
@@ -1054,6 +1128,8 @@ const char *pt_version(void) { return "libptrace 0.1 (gfx950)"; }
 
 const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+unsigned long long pt_allocation_calls(void) { return g_allocation_calls.load(); }
+
 int pt_create(int device_ordinal, pt_context **out_ctx)
 {
     if (!out_ctx) return fail(nullptr, PT_ERR_INVALID, "out_ctx is NULL");
@@ -1080,8 +1156,8 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_refit, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc((void **)&ctx->d_work, kWorkShards * kWorkStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void **)&ctx->d_stats, kStatsShards * kStatsStride * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = dev_malloc((void **)&ctx->d_work, kWorkShards * kWorkStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = dev_malloc((void **)&ctx->d_stats, kStatsShards * kStatsStride * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
@@ -1100,6 +1176,10 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     ctx->sched8_blocks_per_cu = std::max(1, bpc);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_mat_kernel<8>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
     ctx->sched8_ext_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_fast_kernel<4>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched_fast_blocks_per_cu = std::max(1, bpc);
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_sched_fast_kernel<8>, kBlock, 0)) != hipSuccess) return bail("occupancy query", e);
+    ctx->sched8_fast_blocks_per_cu = std::max(1, bpc);
     if (std::getenv("PTRACE_BUILD_TIMING"))
         std::fprintf(stderr, "resident blocks per CU: path_sched_kernel %d, path_sched_mat_kernel %d, path_sched_inst_kernel %d, eight-wide %d and %d\n", ctx->sched_blocks_per_cu, ctx->sched_ext_blocks_per_cu, ctx->sched_inst_blocks_per_cu, ctx->sched8_blocks_per_cu, ctx->sched8_ext_blocks_per_cu);
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, path_pool_kernel<4>, 64, 0)) != hipSuccess) return bail("occupancy query", e);
@@ -1115,6 +1195,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if (const char *env = std::getenv("PTRACE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::min(16, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : std::atoi(env) == 8 ? 8 : 4;
     if (const char *env = std::getenv("PTRACE_BLOCK_ORDER")) ctx->block_order = std::atoi(env) != 0;
+    if (const char *env = std::getenv("PTRACE_FAST_INTRINSICS")) ctx->fast_intrinsics = std::atoi(env) != 0;
     if (const char *env = std::getenv("PTRACE_SPLIT")) ctx->split_budget = std::max(0.0f, std::min(4.0f, (float)std::atof(env)));
     if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = ctx->vote_shade_few = std::max(1, std::min(64, std::atoi(env)));
@@ -1146,12 +1227,12 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices);
     free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices);
-    if (ctx->h_matrices) { (void)hipHostFree(ctx->h_matrices); ctx->h_matrices = nullptr; }
+    if (ctx->h_matrices) { (void)host_free(ctx->h_matrices); ctx->h_matrices = nullptr; }
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
     for (int i = 0; i < pt_context::kCamRing; i++) {
         free_dev(ctx->d_cams[i]);
-        if (ctx->h_cams[i]) (void)hipHostFree(ctx->h_cams[i]);
+        if (ctx->h_cams[i]) (void)host_free(ctx->h_cams[i]);
         if (ctx->ev_cams[i]) (void)hipEventDestroy(ctx->ev_cams[i]);
     }
     if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
@@ -1247,8 +1328,8 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     if (ctx->refit_in_flight) { PT_HIP(ctx, hipEventSynchronize(ctx->ev_refit)); ctx->refit_in_flight = false; }   // d_matrices is free again
     // the matrices go through a pinned buffer of the context's, on its stream: nothing waits here for the frame in flight
     if (ctx->h_matrices_objects < (size_t)n_objects) {
-        if (ctx->h_matrices) { (void)hipHostFree(ctx->h_matrices); ctx->h_matrices = nullptr; ctx->h_matrices_objects = 0; }
-        PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_matrices, (size_t)n_objects * 64, hipHostMallocDefault));
+        if (ctx->h_matrices) { (void)host_free(ctx->h_matrices); ctx->h_matrices = nullptr; ctx->h_matrices_objects = 0; }
+        PT_HIP(ctx, host_malloc((void **)&ctx->h_matrices, (size_t)n_objects * 64, hipHostMallocDefault));
         ctx->h_matrices_objects = (size_t)n_objects;
     }
     for (int o = 0; o < n_objects; o++) std::memcpy(ctx->h_matrices + (size_t)o * 16, objects[o].local_to_world, 64);
@@ -1327,10 +1408,10 @@ int pt_resize(pt_context *ctx, int width, int height)
     free_dev(ctx->own_display);
     ctx->screen_pixels = 0;
     size_t n = (size_t)width * height;
-    PT_HIP(ctx, hipMalloc((void **)&ctx->own_result2, n * sizeof(float4)));
-    PT_HIP(ctx, hipMalloc((void **)&ctx->own_result, n * sizeof(float4)));
-    PT_HIP(ctx, hipMalloc((void **)&ctx->own_conv, n * sizeof(float4)));
-    PT_HIP(ctx, hipMalloc((void **)&ctx->own_ids, n * sizeof(int32_t)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->own_result2, n * sizeof(float4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->own_result, n * sizeof(float4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->own_conv, n * sizeof(float4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->own_ids, n * sizeof(int32_t)));
     // Cleared on the context's stream and waited for: hipMemset returns before a device fill has run and fills on the null
     // stream, which a non-blocking stream does not wait for - the next frame's kernels could read the new targets (recycled
     // memory) before the zeros arrived.
@@ -1387,7 +1468,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
     const bool extended = instanced || ctx->d_mesh_mat || a.render_mode == 3 || a.render_mode == 4 || a.render_mode >= 7;
     // the wavefront stages pack a path's bounce count into 8 bits (pt_wavefront.hpp): longer paths go to the scheduled kernel
     const int width = tree_width(ctx);                // 8: walked by the scheduled kernel only, whatever the backend option says
-    if (ctx->backend == 1 && width != 8 && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary && a.maxb <= 255) return render_wavefront(ctx, a);
+    if (ctx->backend == 1 && width != 8 && !ctx->fast_intrinsics && a.depth == 0 && a.render_mode == 1 && !extended && !a.reuse_primary && a.maxb <= 255) return render_wavefront(ctx, a);
     PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
     {
         // Few samples per pixel: pixels are claimed often, and one counter would serialise the claims at the L2.  Many
@@ -1412,8 +1493,8 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         if (a.n_blocks > ctx->order_capacity) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             free_dev(ctx->d_block_cost); free_dev(ctx->d_block_order); ctx->order_capacity = 0; ctx->order_ready = false;
-            PT_HIP(ctx, hipMalloc((void **)&ctx->d_block_cost, a.n_blocks * sizeof(uint32_t)));
-            PT_HIP(ctx, hipMalloc((void **)&ctx->d_block_order, a.n_blocks * sizeof(uint32_t)));
+            PT_HIP(ctx, dev_malloc((void **)&ctx->d_block_cost, a.n_blocks * sizeof(uint32_t)));
+            PT_HIP(ctx, dev_malloc((void **)&ctx->d_block_order, a.n_blocks * sizeof(uint32_t)));
             ctx->order_capacity = a.n_blocks;
         }
         if (!ctx->order_ready || std::memcmp(key, ctx->order_key, sizeof key) != 0) {
@@ -1437,7 +1518,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
             return PT_OK;
         }
     } after{ctx, a, want_order, key};
-    if (ctx->backend == 2 && !instanced && width != 8) {
+    if (ctx->backend == 2 && !instanced && width != 8 && !ctx->fast_intrinsics) {
         // one wave per block, kPoolK * 64 ray slots per wave
         constexpr int P = 64 * kPoolK;
         const int fit = extended ? ctx->pool_ext_blocks_per_cu : ctx->pool_blocks_per_cu;
@@ -1451,7 +1532,7 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         if (slots > ctx->pool_slots) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             free_dev(ctx->d_pool_state); ctx->pool_slots = 0;
-            PT_HIP(ctx, hipMalloc((void **)&ctx->d_pool_state, slots * 3 * sizeof(float4)));
+            PT_HIP(ctx, dev_malloc((void **)&ctx->d_pool_state, slots * 3 * sizeof(float4)));
             ctx->pool_slots = slots;
         }
         a.stack_overflow = ctx->d_stack_ovf; a.pool_state = ctx->d_pool_state;
@@ -1467,7 +1548,10 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         return after.done();
     }
     int64_t want = ((int64_t)a.total_items + kBlock - 1) / kBlock;
-    const int fit = instanced ? ctx->sched_inst_blocks_per_cu : width == 8 ? (extended ? ctx->sched8_ext_blocks_per_cu : ctx->sched8_blocks_per_cu)
+    // the approximate-arithmetic kernel stands in for the default one only: plain path tracing, no materials, no instances
+    const bool fast = ctx->fast_intrinsics && !extended && !instanced && a.depth == 0;
+    const int fit = instanced ? ctx->sched_inst_blocks_per_cu : fast ? (width == 8 ? ctx->sched8_fast_blocks_per_cu : ctx->sched_fast_blocks_per_cu)
+                              : width == 8 ? (extended ? ctx->sched8_ext_blocks_per_cu : ctx->sched8_blocks_per_cu)
                               : extended ? ctx->sched_ext_blocks_per_cu : ctx->sched_blocks_per_cu;   // a persistent grid: exactly what is resident at once
     const int per_cu = ctx->blocks_per_cu > 0 ? std::min(ctx->blocks_per_cu, fit) : fit;
     int grid = (int)std::min<int64_t>(want, (int64_t)ctx->num_cus * per_cu);
@@ -1483,6 +1567,10 @@ static int launch_path(pt_context *ctx, RenderArgs &a, int x0, int y0, int tw, i
         if (width == 8) hipLaunchKernelGGL(path_sched_mat_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else if (width == 4) hipLaunchKernelGGL(path_sched_mat_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else hipLaunchKernelGGL(path_sched_mat_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    } else if (fast) {
+        if (width == 8) hipLaunchKernelGGL(path_sched_fast_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else if (width == 4) hipLaunchKernelGGL(path_sched_fast_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(path_sched_fast_kernel<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
         if (width == 8) hipLaunchKernelGGL(path_sched_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         else if (width == 4) hipLaunchKernelGGL(path_sched_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
@@ -1516,8 +1604,8 @@ static int ensure_screen_scratch(pt_context *ctx)
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_dev(ctx->d_filtered); free_dev(ctx->d_seeds);
     ctx->screen_pixels = 0;
-    PT_HIP(ctx, hipMalloc((void **)&ctx->d_filtered, (size_t)ctx->W * ctx->H * sizeof(float4)));
-    PT_HIP(ctx, hipMalloc((void **)&ctx->d_seeds, (size_t)ctx->W * ctx->H * sizeof(float)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_filtered, (size_t)ctx->W * ctx->H * sizeof(float4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_seeds, (size_t)ctx->W * ctx->H * sizeof(float)));
     ctx->screen_pixels = (size_t)ctx->W * ctx->H;
     return PT_OK;
 }
@@ -1628,8 +1716,8 @@ static int render_frame(pt_context *ctx, const PtFrameParams *p)
         if (ctx->cams_dirty || !ctx->d_cams[ctx->cam_slot]) {
             const int i = ctx->cam_slot = (ctx->cam_slot + 1) % pt_context::kCamRing;
             if (!ctx->d_cams[i]) {
-                PT_HIP(ctx, hipMalloc((void **)&ctx->d_cams[i], cam_bytes));
-                PT_HIP(ctx, hipHostMalloc((void **)&ctx->h_cams[i], cam_bytes, hipHostMallocDefault));
+                PT_HIP(ctx, dev_malloc((void **)&ctx->d_cams[i], cam_bytes));
+                PT_HIP(ctx, host_malloc((void **)&ctx->h_cams[i], cam_bytes, hipHostMallocDefault));
                 PT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_cams[i], hipEventDisableTiming));
             }
             if (ctx->cams_used[i]) PT_HIP(ctx, hipEventSynchronize(ctx->ev_cams[i]));   // its last reader, kCamRing uploads ago
@@ -1735,6 +1823,11 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         ctx->reuse_primary = value;
         return PT_OK;
     }
+    if (std::strcmp(name, "fast_intrinsics") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: fast_intrinsics must be 0 or 1");
+        ctx->fast_intrinsics = value;
+        return PT_OK;
+    }
     if (std::strcmp(name, "blocks_per_cu") == 0) {
         if (value < 0 || value > 16) return fail(ctx, PT_ERR_INVALID, "pt_set_option: blocks_per_cu must be 0..16");
         ctx->blocks_per_cu = value;
@@ -1773,7 +1866,7 @@ int pt_display_denoise(pt_context *ctx)
     DeviceGuard g(ctx->device);
     if (!ctx->display) {
         if (!ctx->own_display) {
-            PT_HIP(ctx, hipMalloc((void **)&ctx->own_display, (size_t)ctx->W * ctx->H * sizeof(float4)));
+            PT_HIP(ctx, dev_malloc((void **)&ctx->own_display, (size_t)ctx->W * ctx->H * sizeof(float4)));
             PT_HIP(ctx, hipMemsetAsync(ctx->own_display, 0, (size_t)ctx->W * ctx->H * sizeof(float4), ctx->stream));
         }
         ctx->display = ctx->own_display;
@@ -1875,9 +1968,9 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     float *d_od = nullptr, *d_t = nullptr; int32_t *d_id = nullptr;
     auto cleanup = [&] { free_dev(d_od); free_dev(d_t); free_dev(d_id); };
     hipError_t e;
-    if ((e = hipMalloc((void **)&d_od, (size_t)n_rays * 24)) != hipSuccess ||
-        (e = hipMalloc((void **)&d_t, (size_t)n_rays * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&d_id, (size_t)n_rays * 4)) != hipSuccess ||
+    if ((e = dev_malloc((void **)&d_od, (size_t)n_rays * 24)) != hipSuccess ||
+        (e = dev_malloc((void **)&d_t, (size_t)n_rays * 4)) != hipSuccess ||
+        (e = dev_malloc((void **)&d_id, (size_t)n_rays * 4)) != hipSuccess ||
         (e = hipMemcpyAsync(d_od, origins_dirs, (size_t)n_rays * 24, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) {
         cleanup();
         return fail(ctx, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
@@ -1914,10 +2007,12 @@ int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
     // Building or re-inflating the scene allocates; this call does not, so the scene must be ready.
     if (ctx->scene_dirty || (tree_width(ctx) == 2 && (ctx->bvh2_stale || ctx->n_inst)))
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: the scene has changed since it was last built; call pt_render or pt_trace_rays once first");
-    if ((!ctx->spheres.empty() || ctx->n_inst) && reach_needed(ctx, origins_dirs, n_rays, 6) > ctx->sphere_reach)
+    if (ctx->n_prims > 0 && reach_needed(ctx, origins_dirs, n_rays, 6) > ctx->sphere_reach)
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: a ray starts farther from the scene than its tree was built for; call pt_trace_rays once with such rays first");
     unsigned char *base = scratch_of(ctx->device);
     if (!base) return fail(ctx, PT_ERR_UNSUPPORTED, "pt_trace_rays_static: no scratch array on this device (ordinal beyond " + std::to_string(kMaxScratchDevices - 1) + ")");
+    ScratchLease lease(ctx->device);
+    if (!lease.held) return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: the scratch array of this GPU is in use by another call (calls on one GPU must not overlap)");
     DeviceGuard g(ctx->device);
     float *d_od = reinterpret_cast<float *>(base);
     int32_t *d_id = reinterpret_cast<int32_t *>(base + kStaticIds);
@@ -1969,7 +2064,7 @@ int pt_group_create(int n, const int *device_ordinals, pt_group **out_group)
 void pt_group_destroy(pt_group *g)
 {
     if (!g) return;
-    if (g->staging) { DeviceGuard dg(g->staging_device); (void)hipFree(g->staging); }
+    if (g->staging) { DeviceGuard dg(g->staging_device); (void)dev_free(g->staging); }
     if (g->taken) { DeviceGuard dg(g->staging_device); (void)hipEventDestroy(g->taken); }
     for (size_t i = 0; i < g->members.size(); i++) {
         if (g->ready[i]) { DeviceGuard dg(g->members[i]->device); (void)hipEventDestroy(g->ready[i]); }
@@ -2014,10 +2109,10 @@ int pt_group_reduce(pt_group *g, int root)
         DeviceGuard dg(r->device);
         if (g->staging_pixels < pixels || g->staging_device != r->device) {
             PT_GHIP(hipStreamSynchronize(r->stream));
-            if (g->staging) { DeviceGuard old(g->staging_device); (void)hipFree(g->staging); g->staging = nullptr; }
+            if (g->staging) { DeviceGuard old(g->staging_device); (void)dev_free(g->staging); g->staging = nullptr; }
             if (g->taken) { DeviceGuard old(g->staging_device); (void)hipEventDestroy(g->taken); g->taken = nullptr; }
             g->staging_pixels = 0;
-            PT_GHIP(hipMalloc((void **)&g->staging, bytes));
+            PT_GHIP(dev_malloc((void **)&g->staging, bytes));
             PT_GHIP(hipEventCreateWithFlags(&g->taken, hipEventDisableTiming));
             g->staging_pixels = pixels; g->staging_device = r->device;
         }

@@ -300,8 +300,12 @@ bool sky_load_hdr(const char *path, int max_size, int &w, int &h, std::vector<fl
     char sy = 0, sx = 0; int fh = 0, fw = 0;
     if (!std::fgets(line, sizeof line, f) || std::sscanf(line, "%cY %d %cX %d", &sy, &fh, &sx, &fw) != 4 || (sy != '-' && sy != '+') || (sx != '-' && sx != '+') ||
         fw <= 0 || fh <= 0 || fw > 32768 || fh > 32768) { err = "resolution line is not '-Y h +X w'"; return false; }
-    std::vector<unsigned char> scan((size_t)fw * 4);
-    std::vector<float> img((size_t)fw * fh * 4);
+    // a header may claim up to 32768 x 32768 texels (16 GB of floats): the picture is refused rather than the process ended
+    if ((size_t)fw * (size_t)fh > ((size_t)1 << 28)) { err = "picture larger than 2^28 texels"; return false; }
+    std::vector<unsigned char> scan;
+    std::vector<float> img;
+    try { scan.resize((size_t)fw * 4); img.resize((size_t)fw * fh * 4); }
+    catch (const std::bad_alloc &) { err = "out of memory for the picture"; return false; }
     for (int y = 0; y < fh; y++) {
         unsigned char head[4];
         if (std::fread(head, 1, 4, f) != 4) { err = "pixel data ends early"; return false; }
@@ -331,6 +335,9 @@ bool sky_load_hdr(const char *path, int max_size, int &w, int &h, std::vector<fl
                 unsigned char px[4];
                 if (std::fread(px, 1, 4, f) != 4) { err = "pixel data ends early"; return false; }
                 if (px[0] == 1 && px[1] == 1 && px[2] == 1) {
+                    // consecutive repeat texels give the count's bytes, low byte first: a width below 32768 needs two at most,
+                    // and a count of zero would leave x where it is while the shift grows without bound
+                    if (px[3] == 0 || shift > 24) { err = "bad run in a scanline"; return false; }
                     long n = (long)px[3] << shift;
                     if (x + n > fw) { err = "bad run in a scanline"; return false; }
                     while (n--) { std::memcpy(&scan[(size_t)x * 4], &scan[(size_t)(x - 1) * 4], 4); x++; }
@@ -348,7 +355,8 @@ bool sky_load_hdr(const char *path, int max_size, int &w, int &h, std::vector<fl
     }
     while (max_size > 0 && (fw > max_size || fh > max_size) && fw % 2 == 0 && fh % 2 == 0) {
         const int nw = fw / 2, nh = fh / 2;
-        std::vector<float> half((size_t)nw * nh * 4);
+        std::vector<float> half;
+        try { half.resize((size_t)nw * nh * 4); } catch (const std::bad_alloc &) { err = "out of memory for the picture"; return false; }
         for (int y = 0; y < nh; y++)
             for (int x = 0; x < nw; x++)
                 for (int c = 0; c < 4; c++)

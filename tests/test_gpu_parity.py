@@ -1481,3 +1481,52 @@ def test_wavefront_stages_match_golden_vectors_and_oracle(sky_small):
             assert (t.read_hit_ids() == cid).all()
             _assert_same_image(t.read_result(), c, f"wavefront blob70k width {width}")
             assert t.stats()["rays"] == cst["rays"]
+
+
+def test_instances_are_recognised_in_buffers_laid_out_as_the_reference_lays_them_out(sky_small):
+    """RebuildMeshObjectBuffers (RayTracingMaster.cs:387-408) appends, per object, a copy of its mesh's vertices and the
+    mesh's indices offset by that copy's first vertex: objects that share a mesh arrive with DIFFERENT index ranges of
+    equal content.  With option "instancing" they must still share one tree (recognised by content), the image must not
+    change, and a copy that differs in one position or one index must stay out of the group."""
+    f = pa.Scene("fixture")
+    mesh_v = np.array(f.vertices, np.float32).reshape(-1, 3); mesh_i = np.array(f.indices, np.int32)
+    placements = [_trs(0, (-4.0, 1.5, 2.0)), _trs(70, (-1.0, 1.2, 4.0), 0.7), _trs(-130, (2.5, 2.0, 1.0), 1.3, axis=0),
+                  _trs(25, (0.5, 1.4, -2.0), 1.0, axis=2, mirror=True), _trs(200, (4.0, 3.0, 5.0), 2.0), _trs(40, (-3.0, 3.5, 6.0), 1.1)]
+
+    def reference_layout(nudged=None, reindexed=None):
+        verts, index, objs = [], [], np.zeros(len(placements), f.objects.dtype)
+        n_v = n_i = 0
+        for k, m in enumerate(placements):
+            v = mesh_v.copy(); i = mesh_i.copy()
+            if k == nudged:
+                v[17, 1] += 0.25                                    # one position differs: another mesh
+            if k == reindexed:
+                i[0:3] = i[[0, 2, 1]]                               # one triangle wound the other way: another mesh
+            verts.append(v); index.append(i + n_v)                  # indices.Select(index => index + firstVertex)
+            objs[k] = (m, n_i, len(i))
+            n_v += len(v); n_i += len(i)
+        return objs, np.concatenate(verts), np.concatenate(index)
+
+    W, H = 128, 72
+    cam = dict(eye=(0.5, 5.0, -11.0), target=(0.5, 1.5, 2.0), fov=60)
+    p = pa.make_params(f, W, H, spp=2, max_bounces=5, seed=0.77, **cam)
+    nodes = {}
+    with pa.PathTracer(0) as t:
+        t.set_sky(sky_small); t.resize(W, H); t.set_spheres(f.spheres)
+        for label, kw in (("copies", {}), ("one nudged", dict(nudged=2)), ("one reindexed", dict(reindexed=4))):
+            objs, verts, index = reference_layout(**kw)
+            assert len({(int(o["offset"]), int(o["count"])) for o in objs}) == len(objs)            # no two objects share a range
+            c, cid, cst = po.Oracle(f.spheres, objs, verts, index, sky=sky_small).render(p, W, H, threads=4)
+            for inst in (0, 1):
+                t.set_option("instancing", inst)
+                t.set_meshes(objs, verts, index)
+                t.stats(); t.render(p)
+                st = t.stats()
+                assert (t.read_hit_ids() == cid).all(), (label, inst)
+                _assert_same_image(t.read_result(), c, f"{label}, instancing {inst}")
+                assert st["rays"] == cst["rays"]
+                nodes[label, inst] = st["bvh_nodes"]
+        assert (cid > len(f.spheres)).mean() > 0.05
+    assert nodes["copies", 1] < 0.35 * nodes["copies", 0], nodes                  # six copies, one tree
+    assert nodes["copies", 1] < nodes["one nudged", 1] < nodes["copies", 0], nodes            # five share a tree, the nudged copy is flattened
+    assert nodes["copies", 1] < nodes["one reindexed", 1] < nodes["copies", 0], nodes

@@ -414,3 +414,49 @@ def test_frame_whose_camera_ray_meets_the_ground_plane_39_450_units_out(tracer):
     t.render(p)
     for got, want in zip((t.read_result(), t.read_converged(), t.read_target(pa.PT_TARGET_DENOISED)), images[0]):
         assert _same(got, want)
+
+
+@pytest.mark.parametrize("width", [4, 2, 8])
+def test_slivers_seen_from_far_away_keep_the_hits_that_only_rounding_produces(width):
+    """Moeller-Trumbore's barycentrics (RayTracingShader.compute:192-230) err in proportion to the ray origin's distance and to
+    the triangle's thinness: a sliver ten units long and a thousandth wide, seen from 1e3 .. 1e5 units away, reports hits
+    units beyond its end.  The exhaustive loop finds them, so the tree must not prune them: a ray origin beyond the reach
+    the boxes were padded for asks for a build with a larger reach, in scenes without spheres too (the oracle's own tree
+    missed two of 1 500 such rays until it widened its boxes by the triangles' thinness)."""
+    rng = np.random.default_rng(11)
+    a = rng.uniform(-10, 10, (300, 3)); dirs = rng.normal(size=(300, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    side = np.cross(dirs, rng.normal(size=(300, 3))); side /= np.linalg.norm(side, axis=1, keepdims=True)
+    verts = np.stack([a, a + 10 * dirs, a + 10 * dirs + 1e-3 * side], 1).reshape(-1, 3).astype(np.float32)
+    index = np.arange(900, dtype=np.int32)
+    f = pa.Scene("fixture")
+    objs = np.zeros(1, f.objects.dtype); objs[0] = (np.eye(4, dtype=np.float32).reshape(16), 0, 900)
+    sph = np.zeros((0, 14), np.float32)
+    tris = verts.reshape(-1, 3, 3).astype(np.float64)
+    rays = []
+    for _ in range(3000):
+        t = tris[rng.integers(0, len(tris))]
+        dist = 10.0 ** rng.uniform(3, 5)
+        k = rng.integers(0, 3); p0, p1, p2 = t[k], t[(k + 1) % 3], t[(k + 2) % 3]
+        on_edge = p0 + rng.uniform(0.1, 0.9) * (p1 - p0)
+        n = np.cross(t[1] - t[0], t[2] - t[0]); nn = np.linalg.norm(n)
+        outward = np.cross(p1 - p0, n); outward /= np.linalg.norm(outward)
+        if outward @ (p2 - p0) > 0:
+            outward = -outward
+        target = on_edge + outward * 1e-3 * rng.uniform(-0.5, 0.6)
+        dirn = n / nn + 0.7 * rng.normal(size=3); dirn /= np.linalg.norm(dirn)
+        if dirn @ n < 0:
+            dirn = -dirn
+        o = target + dirn * dist
+        d = target - o; d /= np.linalg.norm(d)
+        rays.append(np.concatenate([o, d]))
+    od = np.array(rays, np.float32)
+    want_i, want_t = po.Oracle(sph, objs, verts, index, accel=False).trace_rays(od)
+    acc_i, acc_t = po.Oracle(sph, objs, verts, index, accel=True).trace_rays(od)
+    assert (acc_i == want_i).all() and (acc_t.view(np.uint32) == want_t.view(np.uint32)).all()
+    assert (want_i > 0).sum() > 200
+    with pa.PathTracer(0) as t:
+        t.set_option("bvh_width", width)
+        t.set_spheres(sph); t.set_meshes(objs, verts, index)
+        ib, tb = t.trace_rays(od); ie, te = t.trace_rays(od, brute_force=True)
+        assert (ie == want_i).all() and (te.view(np.uint32) == want_t.view(np.uint32)).all()       # the device's exhaustive loop
+        assert (ib == want_i).all() and (tb.view(np.uint32) == want_t.view(np.uint32)).all()       # and its tree

@@ -305,7 +305,14 @@ def test_radiance_hdr_sky_loader(tmp_path):
     (tmp_path / "short.hdr").write_bytes(raw[:len(raw) // 2])
     (tmp_path / "magic.hdr").write_bytes(b"P6\n" + raw)
     (tmp_path / "xyze.hdr").write_bytes(raw.replace(b"32-bit_rle_rgbe", b"32-bit_rle_xyze"))
-    for name, why in (("short.hdr", "ends early"), ("magic.hdr", "not a Radiance"), ("xyze.hdr", "32-bit_rle_rgbe"), ("absent.hdr", "cannot open")):
+    # hostile files: old-style repeat texels (1, 1, 1, n) with a count of zero never advance while their shift grows, and a
+    # header may claim 32768 x 32768 texels; both are errors, not undefined behaviour or an allocation of 16 GB
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n"
+    (tmp_path / "zero_run.hdr").write_bytes(head + b"-Y 1 +X 4\n" + bytes([9, 9, 9, 128]) + bytes([1, 1, 1, 0]) * 40)
+    (tmp_path / "long_run.hdr").write_bytes(head + b"-Y 1 +X 4\n" + bytes([9, 9, 9, 128]) + bytes([1, 1, 1, 1]) * 40)
+    (tmp_path / "huge.hdr").write_bytes(head + b"-Y 32768 +X 32768\n" + bytes(64))
+    for name, why in (("short.hdr", "ends early"), ("magic.hdr", "not a Radiance"), ("xyze.hdr", "32-bit_rle_rgbe"), ("absent.hdr", "cannot open"),
+                      ("zero_run.hdr", "bad run"), ("long_run.hdr", "bad run"), ("huge.hdr", "larger than")):
         with pytest.raises(ValueError, match=why):
             pa.load_hdr(tmp_path / name)
 

@@ -28,6 +28,12 @@ def _free_device_memory():
     return free.value
 
 
+def _allocation_calls():
+    """hipMalloc / hipFree / hipHostMalloc / hipHostFree calls the library has made so far (it routes every one through a counter)."""
+    from pathtracing_amd import _ffi
+    return _ffi.ptrace().pt_allocation_calls()
+
+
 @pytest.mark.parametrize("width", [4, 2, 8])
 def test_static_ray_query_equals_the_allocating_one(width):
     rng = np.random.default_rng(7 + width)
@@ -40,9 +46,14 @@ def test_static_ray_query_equals_the_allocating_one(width):
         want = [t.trace_rays(od) for od in (first, second)]           # the existing entry point (it also builds the scene)
         assert (want[0][0] > 0).mean() > 0.05 and (want[0][0] == 0).any() and (want[0][0] == -1).any()
         got0 = t.trace_rays_static(first)
-        before = _free_device_memory()
+        before, calls = _free_device_memory(), _allocation_calls()
         got1 = t.trace_rays_static(second)
-        assert _free_device_memory() == before                        # nothing was allocated or freed
+        assert _allocation_calls() == calls                           # not one allocation or release call was made
+        assert _free_device_memory() == before
+        # the control: the allocating entry point makes such calls and leaves free memory as it was, which is why the
+        # free-memory figure alone proves nothing
+        t.trace_rays(second)
+        assert _allocation_calls() >= calls + 6 and _free_device_memory() == before
         for (gi, gt), (wi, wt) in zip((got0, got1), want):
             assert (gi == wi).all() and (gt.view(np.uint32) == wt.view(np.uint32)).all()
         # the exhaustive loop through the same entry point, and the largest call it takes
@@ -75,3 +86,43 @@ def test_static_ray_query_refuses_what_would_need_an_allocation():
         assert len(t.trace_rays_static(np.zeros((0, 6), np.float32))[0]) == 0
     finally:
         t.close()
+
+
+def test_overlapping_static_queries_on_one_gpu_are_refused_not_mixed():
+    """Every context on a GPU shares the one scratch array: while a call holds it, a second call - here from another thread
+    and another context - returns PT_ERR_INVALID ("in use") instead of overwriting the first call's rays; afterwards the
+    array is free again.  Both calls' results, when they do run, are right."""
+    import threading
+    rng = np.random.default_rng(9)
+    s = pa.Scene("blob70k")
+    ts = [pa.PathTracer(0) for _ in range(2)]
+    try:
+        for t in ts:
+            t.load_scene(s, None)
+        rays = [_rays(rng, MAX_RAYS), _rays(rng, MAX_RAYS)]
+        want = [t.trace_rays(r) for t, r in zip(ts, rays)]
+        refused, wrong, done = [0, 0], [0, 0], [0, 0]
+
+        def worker(k):
+            for _ in range(60):
+                try:
+                    gi, gt = ts[k].trace_rays_static(rays[k])
+                except pa.PtraceError as e:
+                    assert "in use" in str(e)
+                    refused[k] += 1
+                    continue
+                done[k] += 1
+                if not ((gi == want[k][0]).all() and (gt.view(np.uint32) == want[k][1].view(np.uint32)).all()):
+                    wrong[k] += 1
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert wrong == [0, 0] and min(done) > 0, (wrong, done, refused)
+        gi, gt = ts[0].trace_rays_static(rays[0])                     # nobody holds the array any more
+        assert (gi == want[0][0]).all()
+    finally:
+        for t in ts:
+            t.close()
