@@ -174,20 +174,23 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                jitter (RayTracingShader.compute:842), so the ray and its hit are the same every time.  Same image;
  *                PtStats.rays then counts only the rays actually traced.
  *   "refit"      1 (default): pt_update_transforms refits the four-wide tree on the device; 0: it rebuilds on the host.
- *   "instancing"  0 (default): every mesh object is flattened into world-space triangle records.  1: mesh objects with the
- *                same object-space triangles - RebuildMeshObjectBuffers (RayTracingMaster.cs:387-408) gives every object
- *                its own copy of its mesh's vertices and indices, so objects sharing a sharedMesh are recognised by the
- *                content of their ranges (equal indices relative to the range's smallest, bit-identical positions), as
- *                are objects handed one common range - whose localToWorld is rotation or mirror x uniform scale +
- *                translation share ONE tree over the mesh's object-space triangles, under a top-level tree with a box per
- *                object; sheared or unevenly scaled objects, meshes used once and meshes under 64 triangles stay
- *                flattened.  Triangle tests still run on world-space vertices transformed as the shader transforms
- *                them, so the image does not change.  Host build time and device memory fall with the number of
- *                copies (38 copies of 262 k triangles: 4.1 s -> 0.08 s, 2.6 M -> 69 k nodes); tracing is slower
- *                (0.55x - 0.75x there).  Four-child tree and scheduled kernel only: "bvh_width" 2 flattens, other
- *                backends fall back to the scheduled kernel.  pt_update_transforms rebuilds the top-level tree on
- *                the host and sends it and the instance table (1.2 ms there); the shared trees stay, on the host and
- *                on the device, until pt_set_meshes or until the scene outgrows the padding they were built with.
+ *   "instancing"  What becomes of mesh objects with the same object-space triangles.  RebuildMeshObjectBuffers
+ *                (RayTracingMaster.cs:387-408) gives every object its own copy of its mesh's vertices and indices, so
+ *                objects sharing a sharedMesh are recognised by the content of their ranges (equal indices relative to
+ *                the range's smallest, bit-identical positions), as are objects handed one common range; meshes used
+ *                once and meshes under 64 triangles are always flattened.  The image is the same in all three.
+ *                2 (default): the shared mesh is built ONCE on the host, as a tree over its object-space triangles;
+ *                the device makes a copy of that tree per object and refits each copy under its object's matrix.
+ *                What the kernels walk is an ordinary flattened world-space tree (any backend, any localToWorld),
+ *                at the flattened tree's speed, that the host never built: 38 copies of 262 k triangles in 76 ms
+ *                instead of 4.2 s, and pt_update_transforms refits it like any flattened scene (1 ms there).
+ *                1: the objects - if placed by rotation or mirror x uniform scale + translation; sheared or unevenly
+ *                scaled ones are flattened - share ONE tree on the device too, under a top-level tree with a box per
+ *                object; triangle tests still run on world-space vertices transformed as the shader transforms them.
+ *                Device memory falls with the number of copies (2.6 M -> 69 k nodes there), tracing is slower (0.55x -
+ *                0.75x); scheduled kernel only; pt_update_transforms rebuilds the top-level tree on the host (1.2 ms).
+ *                0: every mesh object is flattened into world-space triangle records on the host.
+ *                Four-child tree only: "bvh_width" 2 and 8 flatten on the host.
  *   "split_percent"  30 (default): before the tree is built, triangles that span a sixteenth of the scene or more are cut
  *                into several references (boxes holding a part of the triangle each; a leaf still names the whole
  *                triangle), at most this many additional references per hundred triangles of the scene; 0: none.  A

@@ -522,6 +522,53 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
     return out;
 }
 
+Consecutive4 consecutive_layout(BvhResult &bvh)
+{
+    Consecutive4 out;
+    const size_t n = bvh.nodes4.size();
+    if (n == 0) return out;
+    // breadth-first numbering: a node's inner children get consecutive new numbers, in slot order
+    std::vector<int32_t> old_of; old_of.reserve(n);
+    std::vector<int32_t> new_of(n, -1);
+    old_of.push_back(0); new_of[0] = 0;
+    for (size_t head = 0; head < old_of.size(); head++) {
+        const Bvh4Node &nd = bvh.nodes4[(size_t)old_of[head]];
+        for (int k = 0; k < 4; k++)
+            if (((nd.valid >> k) & 1) && nd.child[k] >= 0) { new_of[(size_t)nd.child[k]] = (int32_t)old_of.size(); old_of.push_back(nd.child[k]); }
+    }
+    if (old_of.size() != n) return out;
+    std::vector<Bvh4Node> nodes(n);
+    std::vector<uint32_t> order; order.reserve(bvh.order.size());
+    out.kinds.assign(n, 0); out.first_child.assign(n, 0); out.first_record.assign(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        Bvh4Node nd = bvh.nodes4[(size_t)old_of[i]];
+        out.first_record[i] = (uint32_t)order.size();
+        bool first_inner = true;
+        for (int k = 0; k < 4; k++) {
+            if (!((nd.valid >> k) & 1)) continue;
+            if (nd.child[k] >= 0) {
+                nd.child[k] = new_of[(size_t)nd.child[k]];
+                if (first_inner) { out.first_child[i] = (uint32_t)nd.child[k]; first_inner = false; }
+                out.kinds[i] |= (uint8_t)(1u << (2 * k));
+            } else {
+                const uint32_t enc = (uint32_t)~nd.child[k], first = enc >> 3, count = (enc & 7u) + 1u;
+                if (count > 2) return out;
+                nd.child[k] = ~(int32_t)(((uint32_t)order.size() << 3) | (count - 1));
+                for (uint32_t q = 0; q < count; q++) order.push_back(bvh.order[first + q]);
+                out.kinds[i] |= (uint8_t)((count + 1) << (2 * k));
+            }
+        }
+        nodes[i] = nd;
+    }
+    if (order.size() != bvh.order.size()) return out;
+    for (Bvh4Node &nd : nodes)
+        for (int k = 0; k < 4; k++)
+            if (!((nd.valid >> k) & 1)) nd.child[k] = ~(int32_t)(((uint32_t)order.size() << 3) | 0u);
+    bvh.nodes4.swap(nodes); bvh.order.swap(order);
+    out.ok = true;
+    return out;
+}
+
 // ---------------------------------------------------------------- reference splitting
 namespace {
 

@@ -105,6 +105,14 @@ struct BvhResult {
 // primitive per leaf whatever leaf_size says, and `nodes4` / `order` describe that same tree.
 BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, float traversal_cost = 0.5f, bool wide8 = false);
 
+// Measurement layout (-DPT_NODES_3LOAD): the four-wide tree renumbered so that a node's inner children are consecutive
+// nodes and its leaf children's records consecutive records, both in slot order; a node then needs no links - a first
+// child, a first record and two bits per slot (0 absent, 1 inner node, 2 / 3 leaf of one / two records) - and fits 48
+// bytes, three 16-byte loads instead of four.  Rewrites nodes4 (same structs, links renumbered) and `order`; fills `kinds`
+// (one byte per node) and `first_child` / `first_record`.  Leaves of more than two records are not representable.
+struct Consecutive4 { std::vector<uint8_t> kinds; std::vector<uint32_t> first_child, first_record; bool ok = false; };
+Consecutive4 consecutive_layout(BvhResult &bvh);
+
 // Reference splitting before the build: a large triangle's box is cut at spatial-median planes of the scene box into
 // several smaller boxes ("references"), each holding the part of the triangle on its side of the cuts, so that a long or
 // large triangle no longer inflates every node on the way down to it.  The tree is then built over references; a leaf

@@ -310,6 +310,24 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
     const size_t col = (size_t)sc.n_nodes4;
     const uint4 q0 = q[0], q1 = q[col], q2 = q[2 * col];
     const uint2 q3 = *reinterpret_cast<const uint2 *>(q + 3 * col);
+#elif defined(PT_NODES_3LOAD)
+    // measurement build: 48-byte nodes without links (bvh.hpp, consecutive_layout):
+    //   (org, ex | ey << 8 | ez << 16 | kinds << 24)  (first child, first record, qlo.x, qlo.y)  (qlo.z, qhi.x, qhi.y, qhi.z)
+    const uint4 *q = sc.nodes4 + (size_t)node * 3;
+    const uint4 q0 = q[0], qa = q[1], qb = q[2];
+    uint4 q1;
+    {
+        uint32_t ci = qa.x, li = qa.y, lk[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t k = (q0.w >> (24 + 2 * c)) & 3u;
+            lk[c] = k == 1u ? ci : ~((li << 3) | (k - 2u));
+            ci += k == 1u ? 1u : 0u; li += k >= 2u ? k - 1u : 0u;
+        }
+        q1 = make_uint4(lk[0], lk[1], lk[2], lk[3]);
+    }
+    const uint4 q2 = make_uint4(qa.z, qa.w, qb.x, qb.y);
+    const uint2 q3 = make_uint2(qb.z, qb.w);
 #else
     const uint4 *q = sc.nodes4 + (size_t)node * 4;
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2];

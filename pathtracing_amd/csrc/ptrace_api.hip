@@ -107,8 +107,16 @@ struct pt_context {
     float *d_build_matrices = nullptr;   // the matrices those boxes were cut under
     // two-level scenes: mesh objects that share a mesh and are placed by a rotation, a uniform scale and a translation keep
     // one tree over the mesh's object-space triangles; the top-level tree holds a box per such object
-    int instancing = 0;               // option "instancing"
+    int instancing = 2;               // option "instancing": 0 flatten on the host, 1 two-level tree, 2 (default) shared meshes copied and refitted on the device
     int n_inst = 0;                   // instances in the current build (0: everything flattened)
+    bool expanded = false;            // the last build copied shared trees on the device (instancing 2): no two-child tree exists
+    // what a transform update of such a scene re-runs: the table of copies, per shared mesh its levels (deepest first) and
+    // its copies' range in the table, and the top-level tree's levels
+    struct ExpandedGroup { int32_t *d_level_nodes = nullptr; std::vector<int> level_first; size_t first_inst = 0, n_inst = 0; };
+    int4 *d_exp_inst = nullptr;
+    std::vector<ExpandedGroup> exp_groups;
+    int32_t *d_exp_top_levels = nullptr;
+    std::vector<int> exp_top_first;
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
     float4 *d_inst = nullptr;         // SceneDev::inst
     std::vector<CachedMesh> mesh_cache;
@@ -256,6 +264,7 @@ thread_local std::string g_create_error;
 int tree_width(const pt_context *ctx)
 {
     if (ctx->walk8) return 8;         // set by a build under option bvh_width 8 whose tree fits a lane's stack of groups
+    if (ctx->expanded) return 4;      // copies made on the device exist as a four-wide tree only (its stack need was checked by the build)
     return ctx->bvh_width != 2 && ctx->stack_need4 <= ctx->stack_limit ? 4 : 2;
 }
 // Groups a lane's stack holds when it walks the eight-wide tree (pt_device.hpp, GroupStackT); PTRACE_STACK_LIMIT lowers it too.
@@ -400,8 +409,9 @@ bool same_content(const RangeContent &a, const RangeContent &b, const std::vecto
 }
 
 std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, const std::vector<int32_t> &indices, const std::vector<float> &vertices,
-                                      std::vector<int> &obj_group)
+                                      std::vector<int> &obj_group, std::vector<int32_t> &obj_base, bool any_affine)
 {
+    obj_base.assign(objects.size(), 0);
     std::vector<MeshGroup> groups;
     int min_tris = kMinInstanceTris;
     if (const char *env = std::getenv("PTRACE_INSTANCE_MIN_TRIS")) min_tris = std::max(1, std::atoi(env));
@@ -418,8 +428,10 @@ std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, 
         while (cls < classes.size() && !same_content(classes[cls], rc, indices, vertices)) cls++;
         if (cls == classes.size()) classes.push_back(rc);
         size_t j = i;
-        for (; j < by_range.size() && by_range[j].first == by_range[i].first; j++)
+        for (; j < by_range.size() && by_range[j].first == by_range[i].first; j++) {
             keyed.push_back({{classes[cls].offset, classes[cls].count}, by_range[j].second});
+            obj_base[(size_t)by_range[j].second] = rc.base;
+        }
         i = j;
     }
     std::sort(keyed.begin(), keyed.end());
@@ -430,6 +442,11 @@ std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, 
         g.scale_min = 1e30;
         for (; j < keyed.size() && keyed[j].first == keyed[i].first; j++) {
             const float *m = objects[(size_t)keyed[j].second].local_to_world;
+            if (any_affine) {       // copies refitted in world space need no bound through the inverse map: any matrix will do
+                g.objects.push_back(keyed[j].second);
+                g.scale_min = 1.0; g.inv_norm = 1.0;
+                continue;
+            }
             const double sc = similarity_scale(m);
             if (!(sc >= 1e-3 && sc <= 1e3)) continue;
             double inv[3][4];
@@ -447,6 +464,37 @@ std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, 
         i = j;
     }
     return groups;
+}
+
+void free_expanded(pt_context *ctx)
+{
+    free_dev(ctx->d_exp_inst); free_dev(ctx->d_exp_top_levels);
+    for (pt_context::ExpandedGroup &g : ctx->exp_groups) free_dev(g.d_level_nodes);
+    ctx->exp_groups.clear(); ctx->exp_top_first.clear();
+}
+
+// Every record and its box from the current matrices, then the copies' nodes level by level, then the top-level tree's:
+// the second half of a build with copies made on the device, and all of a transform update of such a scene.
+int refit_expanded(pt_context *ctx, const RefitArgs &ra)
+{
+    hipLaunchKernelGGL(refit_prims_kernel, dim3((unsigned)(((size_t)ra.n_prims + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, ctx->stream, ra);
+    for (const pt_context::ExpandedGroup &g : ctx->exp_groups) {
+        RefitArgs rg = ra; rg.level_nodes = g.d_level_nodes;
+        for (size_t l = 0; l + 1 < g.level_first.size(); l++) {
+            const int first = g.level_first[l], count = g.level_first[l + 1] - first;
+            const size_t tn = g.n_inst * (size_t)count;
+            if (count > 0)
+                hipLaunchKernelGGL(refit_nodes_copies_kernel, dim3((unsigned)((tn + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, ctx->stream, rg,
+                                   (const int4 *)(ctx->d_exp_inst + g.first_inst), (int)g.n_inst, first, count);
+        }
+    }
+    RefitArgs rt = ra; rt.level_nodes = ctx->d_exp_top_levels;
+    for (size_t l = 0; l + 1 < ctx->exp_top_first.size(); l++) {
+        const int first = ctx->exp_top_first[l], count = ctx->exp_top_first[l + 1] - first;
+        if (count > 0) hipLaunchKernelGGL(refit_nodes_kernel, dim3((unsigned)((count + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, ctx->stream, rt, first, count);
+    }
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
 }
 
 // Flatten meshes to world space (RayTracingShader.compute:236-240 applied once
@@ -468,9 +516,13 @@ int rebuild_scene(pt_context *ctx)
     obj_first_tri[ctx->objects.size()] = (uint32_t)nt;
     // ---- which mesh objects become instances of a shared tree
     std::vector<int> obj_group(ctx->objects.size(), -1);
+    std::vector<int32_t> obj_base;          // smallest vertex index of every candidate object's range
     std::vector<MeshGroup> groups;
-#ifndef PT_NODES_SOA
-    if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, ctx->indices, ctx->vertices, obj_group);
+    // instancing 2: shared meshes are built once and copied per object on the device (expand_instances below); the scene the
+    // kernels see is flat, so every backend and the exhaustive ray query work on it unchanged
+    const bool expand = ctx->instancing == 2;
+#if !defined(PT_NODES_SOA) && !defined(PT_NODES_3LOAD)
+    if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, ctx->indices, ctx->vertices, obj_group, obj_base, expand);
 #endif
     ctx->flatten_once = false;
     std::vector<Aabb> group_bounds(groups.size()); std::vector<char> group_bounds_done(groups.size(), 0);
@@ -648,7 +700,8 @@ int rebuild_scene(pt_context *ctx)
         CachedMesh *hit = nullptr;
         for (CachedMesh &cm : ctx->mesh_cache)
             if (cm.indices_offset == g.indices_offset && cm.indices_count == g.indices_count) hit = &cm;
-        if (hit && hit->leaf_size == leaf_size && hit->pad >= pad_need && hit->pad <= 1.3f * pad_need && hit->reach >= reach_need && hit->reach <= 2.0f * reach_need) {
+        // (expanded copies are refitted in world space: any padding the kept tree was built with will do)
+        if (hit && hit->leaf_size == leaf_size && (expand || (hit->pad >= pad_need && hit->pad <= 1.3f * pad_need && hit->reach >= reach_need && hit->reach <= 2.0f * reach_need))) {
             mesh_trees[gi] = hit;
         } else {
         if (!hit) { ctx->mesh_cache.emplace_back(); hit = &ctx->mesh_cache.back(); }
@@ -714,15 +767,25 @@ int rebuild_scene(pt_context *ctx)
     const size_t nRefs = ref_prim.size();                  // top-level references: nR of primitives, then one per instance
 
     const bool want8 = ctx->bvh_width == 8 && nI == 0;
-    BvhResult bvh = build_bvh(boxes, leaf_size, 0, ct, want8);
+    // expanded copies hang off the top-level tree as subtrees: every instance reference needs a leaf of its own
+    BvhResult bvh = build_bvh(boxes, expand && nI ? 1 : leaf_size, 0, ct, want8);
     // the eight-wide tree is walked if a lane's stack holds it; a tree too deep for that (a degenerate chain) is walked as the
     // two-child tree of the same build, whose records follow the other order
     const bool walk8 = want8 && !bvh.nodes8.empty() && bvh.stack_need8 <= group_stack_limit(ctx);
+#ifdef PT_NODES_3LOAD
+    // measurement build: the four-wide tree renumbered for nodes without links (before anything reads `order`)
+    const Consecutive4 c4 = consecutive_layout(bvh);
+    if (!c4.ok) return fail(ctx, PT_ERR_UNSUPPORTED, "PT_NODES_3LOAD: this tree has no link-free layout");
+#endif
     const std::vector<uint32_t> &order = walk8 ? bvh.order8 : bvh.order;
     if (walk8) { bvh.nodes.clear(); bvh.nodes4.clear(); }
     else { bvh.nodes8.clear(); }
     auto t_built = std::chrono::steady_clock::now();
-    if (nI) {
+    if (nI && expand) {
+        const int need = bvh.stack_need4 + blas_stack_need;
+        if (need > ctx->stack_limit) { ctx->flatten_once = true; return rebuild_scene(ctx); }
+        bvh.stack_need4 = need;
+    } else if (nI) {
         // entering an instance costs the exit marker, and a top-level leaf can stack a link per instance record it holds
         const int need = bvh.stack_need4 + leaf_size + 1 + blas_stack_need;
         if (need > ctx->stack_limit) { ctx->flatten_once = true; return rebuild_scene(ctx); }
@@ -768,7 +831,7 @@ int rebuild_scene(pt_context *ctx)
             recs[slot * 3 + 2] = make_float4(e2.x, e2.y, e2.z, objf);
         }
     }
-    if (nI) {
+    if (nI && !expand) {
         // a top-level leaf that holds one instance and nothing else: its parent links to the instance itself
         for (Bvh4Node &nd : bvh.nodes4)
             for (int k = 0; k < 4; k++) {
@@ -788,6 +851,168 @@ int rebuild_scene(pt_context *ctx)
         smat[i * 4 + 3] = make_float4(s.emission[0], s.emission[1], s.emission[2], 0.0f);
     }
     int rc;
+    if (nI && expand) {
+        // ---- option "instancing" 2: one copy of the shared tree per object, made and refitted on the device (pt_refit.hpp)
+        const size_t n_top = bvh.nodes4.size();
+        std::vector<int4> inst_tab(nI);                 // (first node, first record, object, smallest vertex index)
+        std::vector<int32_t> inst_id0(nI);
+        std::vector<size_t> group_first_inst(groups.size() + 1, 0);
+        size_t node_next = n_top, rec_next = nRefs + 1;
+        {
+            // instances were appended group by group, members in scene order
+            size_t ii = 0;
+            for (size_t gi = 0; gi < groups.size(); gi++) {
+                group_first_inst[gi] = ii;
+                const MeshTree &mt = *mesh_trees[gi];
+                for (size_t m = 0; m < groups[gi].objects.size(); m++, ii++) {
+                    const int o = inst_object[ii];
+                    inst_tab[ii] = make_int4((int)node_next, (int)rec_next, o, obj_base[(size_t)o]);
+                    inst_id0[ii] = 1 + nS + (int32_t)obj_first_tri[(size_t)o];
+                    node_next += mt.bvh.nodes4.size();
+                    rec_next += (size_t)groups[gi].indices_count / 3 + 1;
+                }
+            }
+            group_first_inst[groups.size()] = ii;
+        }
+        const size_t total_nodes = node_next, total_recs = rec_next;
+        if (total_recs >= (1u << 27) || total_nodes >= (1u << 30)) return fail(ctx, PT_ERR_UNSUPPORTED, "more than 2^27 primitive records");
+        // top-level levels (an instance reference is a leaf here; its link is patched to the copy's root afterwards)
+        std::vector<int> level(n_top, 0);
+        int max_level = 0;
+        for (size_t n = 0; n < n_top; n++)
+            for (int k = 0; k < 4; k++)
+                if (((bvh.nodes4[n].valid >> k) & 1) && bvh.nodes4[n].child[k] >= 0) {
+                    level[(size_t)bvh.nodes4[n].child[k]] = level[n] + 1;
+                    max_level = std::max(max_level, level[n] + 1);
+                }
+        std::vector<std::vector<int32_t>> top_levels((size_t)max_level + 1);
+        for (size_t n = 0; n < n_top; n++) top_levels[(size_t)level[n]].push_back((int32_t)n);
+        for (Bvh4Node &nd : bvh.nodes4)
+            for (int k = 0; k < 4; k++) {
+                if (nd.child[k] >= 0 || !((nd.valid >> k) & 1)) continue;
+                const uint32_t enc = (uint32_t)~nd.child[k];
+                const uint32_t prim = ref_prim[order[enc >> 3]];             // leaves hold one reference each
+                if (prim >= nP) nd.child[k] = inst_tab[prim - nP].x;          // the copy's root: an inner node like any other
+            }
+        // top-level slots: where a refit takes each record from
+        std::vector<int4> slot_src(nRefs + 1, make_int4(-1, 0, 0, 0));
+        {
+            size_t j = 0;
+            std::vector<int4> tri_src(tris.size());
+            for (size_t o = 0; o < ctx->objects.size(); o++) {
+                if (obj_group[o] >= 0) continue;
+                const PtMeshObject &mo = ctx->objects[o];
+                const int32_t end = mo.indices_offset + mo.indices_count;
+                for (int32_t i = mo.indices_offset; i + 2 < end; i += 3, j++) tri_src[j] = make_int4((int)o, ctx->indices[i], ctx->indices[i + 1], ctx->indices[i + 2]);
+            }
+            for (size_t slot = 0; slot < nRefs; slot++) {
+                const uint32_t prim = ref_prim[order[slot]];
+                if (prim < nP && (int)prim >= nS) slot_src[slot] = tri_src[prim - nS];
+            }
+        }
+        free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices); free_dev(ctx->d_nodes); free_dev(ctx->d_nodes8);
+        free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_slot_src); free_dev(ctx->d_prim_box); free_dev(ctx->d_node_box);
+        free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices); free_dev(ctx->d_level_nodes);
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_nodes4, total_nodes * sizeof(Bvh4Node)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_prims, total_recs * 3 * sizeof(float4)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_slot_src, total_recs * sizeof(int4)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_prim_box, total_recs * 6 * sizeof(float)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_node_box, total_nodes * 6 * sizeof(float)));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_nodes4, bvh.nodes4.data(), n_top * sizeof(Bvh4Node), hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_prims, recs.data(), (nRefs + 1) * 3 * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_slot_src, slot_src.data(), (nRefs + 1) * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<float> mats(ctx->objects.size() * 16);
+        for (size_t o = 0; o < ctx->objects.size(); o++) std::memcpy(&mats[o * 16], ctx->objects[o].local_to_world, 64);
+        if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)))) return rc;
+        if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
+        int32_t *d_id0 = nullptr;
+        struct Temp { std::vector<void *> p; ~Temp() { for (void *q : p) (void)dev_free(q); } } temp;
+        free_expanded(ctx);
+        if ((rc = upload(ctx, ctx->d_exp_inst, inst_tab.data(), nI * sizeof(int4)))) return rc;
+        int4 *const d_inst_tab = ctx->d_exp_inst;
+        if ((rc = upload(ctx, d_id0, inst_id0.data(), nI * sizeof(int32_t)))) return rc;
+        temp.p.push_back(d_id0);
+        RefitArgs ra;
+        ra.slot_src = ctx->d_slot_src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = ctx->d_prims;
+        ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.nodes8 = nullptr; ra.node_box = ctx->d_node_box; ra.level_nodes = nullptr;
+        ra.pad = pad; ra.sphere_slack2 = sphere_slack2; ra.reach = reach; ra.n_prims = (int32_t)total_recs;
+        ra.slot_clip = nullptr; ra.build_matrices = nullptr;
+        ctx->exp_groups.assign(groups.size(), pt_context::ExpandedGroup());
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            const MeshTree &mt = *mesh_trees[gi];
+            const size_t n_mesh_nodes = mt.bvh.nodes4.size(), n_mesh_slots = (size_t)groups[gi].indices_count / 3;
+            const size_t gI = group_first_inst[gi + 1] - group_first_inst[gi];
+            std::vector<int4> mslots(n_mesh_slots);
+            const int32_t base_rep = obj_base[(size_t)groups[gi].objects[0]];
+            for (size_t sl = 0; sl < n_mesh_slots; sl++) {
+                const uint32_t t = mt.bvh.order[sl];
+                const int32_t *ix = &ctx->indices[(size_t)groups[gi].indices_offset + 3 * (size_t)t];
+                mslots[sl] = make_int4(ix[0] - base_rep, ix[1] - base_rep, ix[2] - base_rep, (int)t);
+            }
+            // the mesh tree's levels, deepest first (nodes are stored parents first)
+            std::vector<int> mlevel(n_mesh_nodes, 0);
+            int mmax = 0;
+            for (size_t n = 0; n < n_mesh_nodes; n++)
+                for (int k = 0; k < 4; k++)
+                    if (((mt.bvh.nodes4[n].valid >> k) & 1) && mt.bvh.nodes4[n].child[k] >= 0) {
+                        mlevel[(size_t)mt.bvh.nodes4[n].child[k]] = mlevel[n] + 1;
+                        mmax = std::max(mmax, mlevel[n] + 1);
+                    }
+            std::vector<int> count((size_t)mmax + 2, 0);
+            for (size_t n = 0; n < n_mesh_nodes; n++) count[(size_t)(mmax - mlevel[n]) + 1]++;
+            for (int l = 0; l <= mmax; l++) count[(size_t)l + 1] += count[(size_t)l];
+            std::vector<int32_t> lnodes(n_mesh_nodes);
+            std::vector<int> cursor(count.begin(), count.end() - 1);
+            for (size_t n = 0; n < n_mesh_nodes; n++) lnodes[(size_t)cursor[(size_t)(mmax - mlevel[n])]++] = (int32_t)n;
+            ctx->exp_groups[gi].level_first = count;
+            ctx->exp_groups[gi].first_inst = group_first_inst[gi]; ctx->exp_groups[gi].n_inst = gI;
+            uint4 *d_mnodes = nullptr; int4 *d_mslots = nullptr;
+            if ((rc = upload(ctx, d_mnodes, mt.bvh.nodes4.data(), n_mesh_nodes * sizeof(Bvh4Node)))) return rc;
+            temp.p.push_back(d_mnodes);
+            if ((rc = upload(ctx, d_mslots, mslots.data(), n_mesh_slots * sizeof(int4)))) return rc;
+            temp.p.push_back(d_mslots);
+            if ((rc = upload(ctx, ctx->exp_groups[gi].d_level_nodes, lnodes.data(), lnodes.size() * sizeof(int32_t)))) return rc;
+            ExpandArgs ea;
+            ea.mesh_nodes = d_mnodes; ea.mesh_slots = d_mslots; ea.inst = d_inst_tab + group_first_inst[gi]; ea.inst_id0 = d_id0 + group_first_inst[gi];
+            ea.n_mesh_nodes = (int32_t)n_mesh_nodes; ea.n_mesh_slots = (int32_t)n_mesh_slots; ea.n_inst = (int32_t)gI;
+            ea.nodes4 = ctx->d_nodes4; ea.prims = ctx->d_prims; ea.slot_src = ctx->d_slot_src;
+            const size_t tn = gI * n_mesh_nodes, ts = gI * (n_mesh_slots + 1);
+            hipLaunchKernelGGL(expand_nodes_kernel, dim3((unsigned)((tn + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, ctx->stream, ea);
+            hipLaunchKernelGGL(expand_slots_kernel, dim3((unsigned)((ts + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, ctx->stream, ea);
+        }
+        PT_HIP(ctx, hipGetLastError());
+        {
+            std::vector<int32_t> tl;
+            ctx->exp_top_first.clear();
+            for (int l = max_level; l >= 0; l--) { ctx->exp_top_first.push_back((int)tl.size()); tl.insert(tl.end(), top_levels[(size_t)l].begin(), top_levels[(size_t)l].end()); }
+            ctx->exp_top_first.push_back((int)tl.size());
+            if ((rc = upload(ctx, ctx->d_exp_top_levels, tl.data(), tl.size() * sizeof(int32_t)))) return rc;
+        }
+        if ((rc = refit_expanded(ctx, ra))) return rc;
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));       // the temporaries go when this returns
+        ctx->n_inst = 0; ctx->inst_sig.clear(); ctx->inst_node_cap = ctx->inst_rec_cap = 0;
+        ctx->refit_ready = ctx->refit != 0;                    // a transform update re-runs the refit passes over the copies (refit_expanded)
+        ctx->walk8 = false; ctx->n_nodes8 = 0; ctx->stack_need8 = 0;
+        ctx->n_nodes4 = (int)total_nodes; ctx->n_nodes = (int)total_nodes;     // no two-child tree: n_nodes only says "there is a tree"
+        ctx->n_prims = (int)nIds; ctx->n_slots = (int)total_recs; ctx->n_top_records = (int)total_recs; ctx->n_spheres = nS;
+        ctx->stack_need4 = bvh.stack_need4;
+        ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
+        ctx->expanded = true;
+        ctx->stats.bvh_nodes = (int)total_nodes; ctx->stats.bvh_prims = ctx->n_prims;
+        ctx->stats.bvh_depth = bvh.depth4 + [&] { int d = 0; for (const MeshTree *mt : mesh_trees) d = std::max(d, mt->bvh.depth4); return d; }();
+        ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (std::getenv("PTRACE_BUILD_TIMING"))
+            std::fprintf(stderr, "scene build (copies made on the device): %zu primitives, %zu copies of %zu meshes, %zu nodes; prepare %.1f ms, trees %.1f ms, device %.1f ms\n", nIds, nI, groups.size(), total_nodes,
+                         std::chrono::duration<float, std::milli>(t_prep - t0).count(), std::chrono::duration<float, std::milli>(t_built - t_prep).count(),
+                         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_built).count());
+        ctx->scene_dirty = false;
+        ctx->bvh2_stale = false;
+        return PT_OK;
+    }
+    ctx->expanded = false;
+    free_expanded(ctx);
     // ---- two-level scenes: the mesh trees follow the top-level tree in the node and record arrays; instance table
     ctx->n_inst = (int)nI;
     size_t real_nodes4 = bvh.nodes4.size();                // without the room left after the top level of a two-level scene
@@ -923,6 +1148,22 @@ int rebuild_scene(pt_context *ctx)
         if ((rc = upload(ctx, ctx->d_nodes4, cols.data(), cols.size() * sizeof(uint4)))) return rc;
         ctx->refit_ready = false;          // the refit kernels write whole records
     }
+#elif defined(PT_NODES_3LOAD)
+    {
+        const size_t n4 = bvh.nodes4.size();
+        std::vector<uint4> packed(n4 * 3);
+        for (size_t n = 0; n < n4; n++) {
+            const Bvh4Node &nd = bvh.nodes4[n];
+            uint32_t w[12];
+            std::memcpy(&w[0], nd.org, 12);
+            w[3] = (uint32_t)nd.ex | ((uint32_t)nd.ey << 8) | ((uint32_t)nd.ez << 16) | ((uint32_t)c4.kinds[n] << 24);
+            w[4] = c4.first_child[n]; w[5] = c4.first_record[n];
+            std::memcpy(&w[6], nd.qlo, 12); std::memcpy(&w[9], nd.qhi, 12);
+            std::memcpy(&packed[n * 3], w, 48);
+        }
+        if ((rc = upload(ctx, ctx->d_nodes4, packed.data(), packed.size() * sizeof(uint4)))) return rc;
+        ctx->refit_ready = false;          // the refit kernels write 64-byte records
+    }
 #else
     if (!keep_mesh_trees && (rc = upload(ctx, ctx->d_nodes4, bvh.nodes4.data(), bvh.nodes4.size() * sizeof(Bvh4Node)))) return rc;
 #endif
@@ -971,6 +1212,7 @@ int rebuild_scene(pt_context *ctx);
 int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
 {
     if (tree_width(ctx) == 2 && (ctx->bvh2_stale || ctx->n_inst)) ctx->scene_dirty = true;   // the two-child tree is flat and never refitted
+    if (ctx->expanded && ctx->bvh_width != 4) ctx->scene_dirty = true;                        // another width: a host build of the flattened scene
     for (int pass = 0; pass < 2; pass++) {
         if (ctx->scene_dirty) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1227,6 +1469,7 @@ void pt_destroy(pt_context *ctx)
     free_dev(ctx->d_work); free_dev(ctx->d_stats); free_dev(ctx->d_stack_ovf);
     free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices);
     free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices);
+    free_expanded(ctx);
     if (ctx->h_matrices) { (void)host_free(ctx->h_matrices); ctx->h_matrices = nullptr; }
     free_dev(ctx->d_slot_src); free_dev(ctx->d_vertices); free_dev(ctx->d_matrices); free_dev(ctx->d_prim_box);
     free_dev(ctx->d_node_box); free_dev(ctx->d_level_nodes); free_dev(ctx->d_mesh_mat);
@@ -1339,6 +1582,11 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.nodes8 = ctx->d_nodes8; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
     ra.pad = ctx->box_pad; ra.sphere_slack2 = ctx->sphere_slack2; ra.reach = ctx->sphere_reach; ra.n_prims = ctx->n_slots;
     ra.slot_clip = ctx->d_slot_clip; ra.build_matrices = ctx->d_build_matrices;
+    if (ctx->expanded) {
+        ra.slot_clip = nullptr; ra.build_matrices = nullptr;
+        int rc = refit_expanded(ctx, ra);
+        if (rc) return rc;
+    } else {
     hipLaunchKernelGGL(refit_prims_kernel, dim3((ctx->n_slots + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra);
     for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
         const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
@@ -1346,6 +1594,7 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
             hipLaunchKernelGGL(refit_nodes8_kernel, dim3((count + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra, first, count);
         else if (count > 0)
             hipLaunchKernelGGL(refit_nodes_kernel, dim3((count + kRefitBlock - 1) / kRefitBlock), dim3(kRefitBlock), 0, ctx->stream, ra, first, count);
+    }
     }
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipEventRecord(ctx->ev_refit, ctx->stream));
@@ -1840,7 +2089,7 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         return PT_OK;
     }
     if (std::strcmp(name, "instancing") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, PT_ERR_INVALID, "pt_set_option: instancing must be 0 or 1");
+        if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: instancing must be 0, 1 or 2");
         if (ctx->instancing != value) ctx->scene_dirty = true;
         ctx->instancing = value;
         return PT_OK;

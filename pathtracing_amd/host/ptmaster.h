@@ -104,7 +104,8 @@ int ptm_master_set_camera(ptm_master *m, const float eye[3], const float target[
 /* renderScale + GetRenderScale (RayTracingMaster.cs:86,585-597): the render size becomes Mathf.RoundToInt(screen size *
  * renderScale) in place of the width / height of ptm_master_configure.  All targets get that size; the reference gives
  * _converged and denoisedTex the screen size instead (:563-571), which differs for renderScale != 1 only
- * (TestScene.unity:783 has 1). */
+ * (TestScene.unity:783 has 1): at such a scale ptm_master_render renders renderMode 1, which reads neither, and returns
+ * PT_ERR_UNSUPPORTED for every other renderMode. */
 int ptm_master_set_render_scale(ptm_master *m, int screen_width, int screen_height, float render_scale);
 void ptm_master_render_size(const ptm_master *m, int32_t size[2]);
 /* RayTracingMaster.RegisterObject / UnregisterObject / UpdateObject (RayTracingMaster.cs:296-313), which the reference's

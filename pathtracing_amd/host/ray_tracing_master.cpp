@@ -278,6 +278,15 @@ int RayTracingMaster::Render()
     if ((rc = SetShaderParameters(p))) return rc;         // :716
     if ((rc = InitRenderTexture())) return rc;            // :718
     if (targetW_ == 0 || targetH_ == 0) return PT_OK;     // :721
+    // :563-576 gives _converged, denoisedTex and normalTex (int)(RenderWidth / renderScale) texels a side - the screen size -
+    // while _target has the render size; every target here has the render size.  The two agree for renderScale 1
+    // (TestScene.unity:783) and whenever the division gives the render size back; renderMode 1 reads none of those
+    // targets.  Any other combination would show a history of another size than the reference's: refused, not approximated.
+    if (renderMode != 1 && ((int)((float)RenderWidth / renderScale) != RenderWidth || (int)((float)RenderHight / renderScale) != RenderHight)) {
+        error_ = "Render: renderScale " + std::to_string(renderScale) + " gives the history targets (_converged, denoisedTex: RayTracingMaster.cs:563-571) "
+                 "another size than the render target; only renderMode 1 is supported at this scale";
+        return PT_ERR_UNSUPPORTED;
+    }
     if ((rc = check(pt_render(ctx_, &p), "pt_render"))) return rc;   // :735-747
     frame_++;
     counter_++;                                           // :737

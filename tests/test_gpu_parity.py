@@ -1517,7 +1517,7 @@ def test_instances_are_recognised_in_buffers_laid_out_as_the_reference_lays_them
             objs, verts, index = reference_layout(**kw)
             assert len({(int(o["offset"]), int(o["count"])) for o in objs}) == len(objs)            # no two objects share a range
             c, cid, cst = po.Oracle(f.spheres, objs, verts, index, sky=sky_small).render(p, W, H, threads=4)
-            for inst in (0, 1):
+            for inst in (0, 1, 2):
                 t.set_option("instancing", inst)
                 t.set_meshes(objs, verts, index)
                 t.stats(); t.render(p)
@@ -1527,6 +1527,30 @@ def test_instances_are_recognised_in_buffers_laid_out_as_the_reference_lays_them
                 assert st["rays"] == cst["rays"]
                 nodes[label, inst] = st["bvh_nodes"]
         assert (cid > len(f.spheres)).mean() > 0.05
+        # instancing 2 - the shared tree copied and refitted per object on the device - is an ordinary flat tree: the exhaustive
+        # loop agrees with it on random rays, the other kernels walk it, and it follows the objects when they move
+        rng = np.random.default_rng(6)
+        o = rng.uniform(-8, 8, (2000, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.3, 8, 2000)
+        d = rng.normal(size=(2000, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        od = np.concatenate([o, d], 1)
+        objs, verts, index = reference_layout()
+        t.set_option("instancing", 2); t.set_meshes(objs, verts, index)
+        ib, tb = t.trace_rays(od); ie, te = t.trace_rays(od, brute_force=True)
+        assert (ib == ie).all() and (_bits(tb) == _bits(te)).all() and (ib > len(f.spheres)).mean() > 0.02
+        c, cid, cst = po.Oracle(f.spheres, objs, verts, index, sky=sky_small).render(p, W, H, threads=4)
+        for backend in (2, 1, 0):
+            t.set_option("backend", backend); t.render(p)
+            assert (t.read_hit_ids() == cid).all(), backend
+            _assert_same_image(t.read_result(), c, f"copies on the device, backend {backend}")
+        moved = objs.copy()
+        moved["m"][1] = _trs(110, (-1.5, 1.6, 3.0), 0.9); moved["m"][3] = _trs(-60, (3.0, 2.2, -1.0), 1.4, axis=0)
+        sheared = _trs(0, (5.0, 1.6, 3.0)).reshape(4, 4).copy(); sheared[1, 0] = 0.4          # not a similarity: fine for copies in world space
+        moved["m"][5] = sheared.reshape(16)
+        t.update_transforms(moved); t.render(p)
+        c2, cid2, _ = po.Oracle(f.spheres, moved, verts, index, sky=sky_small).render(p, W, H, threads=4)
+        assert (t.read_hit_ids() == cid2).all()
+        _assert_same_image(t.read_result(), c2, "copies on the device, objects moved")
     assert nodes["copies", 1] < 0.35 * nodes["copies", 0], nodes                  # six copies, one tree
     assert nodes["copies", 1] < nodes["one nudged", 1] < nodes["copies", 0], nodes            # five share a tree, the nudged copy is flattened
     assert nodes["copies", 1] < nodes["one reindexed", 1] < nodes["copies", 0], nodes
+    assert 5 * nodes["copies", 1] < nodes["copies", 2] < 1.5 * nodes["copies", 0], nodes       # a flat tree again, made of six copies of the shared one

@@ -268,6 +268,12 @@ def test_master_mirror_render_scale():
         assert pt.pt_read_result(lib.ptm_master_context(h), got.ctypes.data) == 0
         c, _, _ = po.Oracle.from_scene(s, pa.procedural_sky(64, 32), accel=False).render(p, W, H, threads=4)
         assert _same(got, c)
+        # the history targets of the reference keep the screen size at such a scale (RayTracingMaster.cs:563-571): the modes that
+        # read them are refused by name, and accepted again at a scale that gives the render size back
+        lib.ptm_master_set_render_mode(h, 2)
+        assert lib.ptm_master_render(h) == pa.PT_ERR_UNSUPPORTED and b"renderScale" in lib.ptm_master_error(h)
+        assert lib.ptm_master_set_render_scale(h, 64, 36, 1.0) == 0
+        assert lib.ptm_master_render(h) == 0, lib.ptm_master_error(h)
         assert lib.ptm_master_set_render_scale(h, 64, 36, 0.0) != 0
     finally:
         lib.ptm_master_destroy(h)

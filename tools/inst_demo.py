@@ -1,5 +1,5 @@
-"""Two-level tree against the flattened one on city10m (38 placements of the 262 k-triangle hall): build time, tree size,
-rays per second and the image checksum for option "instancing" 0 and 1.
+"""Two-level tree (option "instancing" 1) and copies made on the device (2) against the host-built flattened tree (0) on
+city10m (38 placements of the 262 k-triangle hall): build time, tree size, rays per second and the image checksum.
 usage: python tools/inst_demo.py [width height spp]"""
 import os
 import sys
@@ -17,7 +17,7 @@ def main():
     scene = pa.Scene(os.environ.get("SCENE", "city10m"))
     sky = pa.procedural_sky(512, 256)
     print(f"{scene.name}: {scene.n_triangles} triangles in {len(scene.objects)} mesh objects", flush=True)
-    for inst in (0, 1):
+    for inst in (int(x) for x in os.environ.get("INST", "0 1 2").split()):
         with pa.PathTracer(0) as tr:
             tr.set_option("instancing", inst)
             t0 = time.time()

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything the round-3 profile files are made from, in one call on the GPU box (outputs under gpurun_out/r03p/).
+# Needs the measurement builds csrc/libptrace_prof.so (-DPT_PROFILE_PHASES) and csrc/libptrace_w4.so (-DPT_SCHED_WAVES=4).
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $REPO
+O=gpurun_out/r03p; mkdir -p $O
+tools/profile_gpu.sh r03 > $O/profile_gpu.log 2>&1; cp gpurun_out/prof_r03/summary.txt $O/rocprofv3_summary_sched.txt
+echo "profile_gpu done"
+(tools/ab_width.sh hall260k blob70k; BENCH_ARGS="--spp 4" tools/ab_width.sh city10m) > $O/width_ab.txt 2>&1
+echo "width ab done"
+for sc in hall260k blob70k; do for w in 4 8; do echo "== $sc width $w"; PTRACE_BVH_WIDTH=$w tools/pmc_quick.sh ${sc}_w$w --scene $sc; done; done > $O/width_pmc.txt 2>&1
+for w in 4 8; do echo "== city10m width $w (4 spp)"; PTRACE_BVH_WIDTH=$w tools/pmc_quick.sh city_w$w --scene city10m --spp 4; done >> $O/width_pmc.txt 2>&1
+echo "width pmc done"
+(echo "== width 4, exact"; tools/phase_profile.sh; echo "== width 4, fast_intrinsics"; PTRACE_FAST_INTRINSICS=1 tools/phase_profile.sh; echo "== width 8, exact"; PTRACE_BVH_WIDTH=8 tools/phase_profile.sh) 2>&1 | cut -c1-300 > $O/phase_profile.txt
+timeout -k 10 300 python -u tools/fast_rmse.py > $O/fast_intrinsics.txt 2>&1
+echo "phase + fast done"
+(PTRACE_BLOCK_ORDER=1 tools/pmc_write.sh order1; tools/pmc_write_size.sh base; LIB=libptrace_w4.so tools/pmc_write_size.sh w4; LIB=libptrace_w4.so WIDTHS=4 tools/ab_width.sh hall260k) > $O/write_traffic.txt 2>&1
+tools/trace_modes.sh > $O/trace_modes.log 2>&1; cp gpurun_out/prof_modes/summary.txt $O/modes_summary.txt
+PTRACE_BUILD_TIMING=1 timeout -k 10 500 python -u tools/inst_demo.py > $O/instancing.txt 2>&1
+tools/trace_default.sh > $O/trace_default.log 2>&1; cp gpurun_out/prof_pipelined/summary.txt $O/pipelined_trace.txt
+echo "traffic, modes, instancing, pipelined done"
+timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err
+tail -c 400 $O/bench.json

@@ -96,7 +96,7 @@ def run(budget=60.0, seed=1):
         width = int(rng.choice([2, 4, 8]))
         t.set_option("bvh_width", width)
         t.set_option("split_percent", int(rng.choice([0, 30, 30, 400])))
-        t.set_option("instancing", int(rng.random() < 0.6))
+        t.set_option("instancing", int(rng.choice([0, 1, 1, 2, 2])))
         t.set_spheres(sph); t.set_meshes(objs, v, idx); t.set_sky(sky); t.resize(W, H)
         t.set_mesh_materials(mats)
         orc = po.Oracle(sph, objs, v, idx, sky=sky, accel=False, materials=mats)
