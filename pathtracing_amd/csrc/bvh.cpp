@@ -225,7 +225,7 @@ void quantise(const Aabb &pb, const float cell[3], const Aabb &cb, uint8_t ql[3]
 constexpr float kWideNodeCost = 1.0f, kWidePrimCost = 0.35f;
 struct WideDp { float c[8]; uint8_t take[8]; uint8_t node_at; };
 
-void wide_dp(const std::vector<Tmp> &tmp, int32_t n_tmp, int32_t root, std::vector<WideDp> &dp, float prim_cost)
+void wide_dp(const std::vector<Tmp> &tmp, int32_t n_tmp, int32_t root, std::vector<WideDp> &dp, float prim_cost, int width = 8, float leaf_cost = 0.0f)
 {
     dp.resize((size_t)n_tmp);
     // areas relative to the root's, so that the sums stay finite whatever the scene's scale; a box without area (or with an
@@ -239,14 +239,14 @@ void wide_dp(const std::vector<Tmp> &tmp, int32_t n_tmp, int32_t root, std::vect
         if (!(area <= 1.0f)) area = 1.0f;
         area += 1e-7f;
         if (t.count) {                       // a primitive
-            for (int i = 0; i < 8; i++) { d.c[i] = area * prim_cost * (float)t.count; d.take[i] = 0; }
+            for (int i = 0; i < 8; i++) { d.c[i] = area * (leaf_cost + prim_cost * (float)t.count); d.take[i] = 0; }
             d.node_at = 0;
             continue;
         }
         const WideDp &l = dp[(size_t)t.left], &r = dp[(size_t)t.right];
         float dist[8];                       // dist[j - 1] = D(n, j), j >= 2
         dist[0] = kInf;
-        for (int j = 2; j <= 8; j++) {
+        for (int j = 2; j <= width; j++) {
             float best = kInf; int bk = 1;
             for (int k = 1; k < j; k++) {
                 const float c = l.c[k - 1] + r.c[j - k - 1];
@@ -254,9 +254,9 @@ void wide_dp(const std::vector<Tmp> &tmp, int32_t n_tmp, int32_t root, std::vect
             }
             dist[j - 1] = best; d.take[j - 1] = (uint8_t)bk;
         }
-        d.c[0] = area * kWideNodeCost + dist[7];
+        d.c[0] = area * kWideNodeCost + dist[width - 1];
         d.node_at = 1;
-        for (int i = 2; i <= 8; i++) {
+        for (int i = 2; i <= width; i++) {
             if (d.c[0] <= dist[i - 1]) { d.c[i - 1] = d.c[0]; d.node_at |= (uint8_t)(1u << (i - 1)); }
             else d.c[i - 1] = dist[i - 1];
         }
@@ -454,12 +454,26 @@ BvhResult build_bvh(const std::vector<Aabb> &boxes, int leaf_size, int threads, 
     std::vector<Item4> st4;
     st4.push_back({root, -1, 0, 1, 0});
     out.nodes4.reserve(out.nodes.size() / 2 + 1);
+    std::vector<WideDp> dp4;
+    bool use_dp4 = false;
+    if (const char *env = std::getenv("PTRACE_COLLAPSE4")) {         // measurement knob: "prim cost,leaf cost"
+        float pc = 0.35f, lc = 0.0f;
+        std::sscanf(env, "%f,%f", &pc, &lc);
+        wide_dp(tmp, b.next.load(), root, dp4, pc, 4, lc);
+        use_dp4 = true;
+    }
     while (!st4.empty()) {
         Item4 it = st4.back(); st4.pop_back();
         const Tmp &t = tmp[it.tmp_index];
         int32_t kids[4] = {t.left, t.right, -1, -1};
         int nk = 2;
-        while (nk < 4) {
+        if (use_dp4) {
+            nk = 0;
+            const int k = dp4[(size_t)it.tmp_index].take[3];
+            wide_slots(tmp, dp4, t.left, k, kids, nk);
+            wide_slots(tmp, dp4, t.right, 4 - k, kids, nk);
+        }
+        while (!use_dp4 && nk < 4) {
             int best = -1; float best_area = -1.0f;
             for (int k = 0; k < nk; k++)
                 if (tmp[kids[k]].count == 0) {

@@ -21,6 +21,7 @@
 #include "pt_pool.hpp"
 #include "pt_screen.hpp"
 #include "pt_refit.hpp"
+#include "pt_build.hpp"
 
 using namespace ptrace;
 
@@ -118,6 +119,10 @@ struct pt_context {
     int32_t *d_exp_top_levels = nullptr;
     std::vector<int> exp_top_first;
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
+    // option "tree_build": 0 the host's binned-SAH builder, 1 the device builder (pt_build.hpp) for whatever is not a copy of a
+    // shared mesh, 2 (default) the device builder for scenes of kDeviceBuildMinPrims primitives or more
+    int tree_build = 2;
+    bool device_built = false;        // the last build ran on the device: a four-wide tree only, like `expanded`
     float4 *d_inst = nullptr;         // SceneDev::inst
     std::vector<CachedMesh> mesh_cache;
     uint64_t mesh_versions = 0;
@@ -264,7 +269,7 @@ thread_local std::string g_create_error;
 int tree_width(const pt_context *ctx)
 {
     if (ctx->walk8) return 8;         // set by a build under option bvh_width 8 whose tree fits a lane's stack of groups
-    if (ctx->expanded) return 4;      // copies made on the device exist as a four-wide tree only (its stack need was checked by the build)
+    if (ctx->expanded || ctx->device_built) return 4;      // trees made on the device exist four-wide only (their stack need was checked by the build)
     return ctx->bvh_width != 2 && ctx->stack_need4 <= ctx->stack_limit ? 4 : 2;
 }
 // Groups a lane's stack holds when it walks the eight-wide tree (pt_device.hpp, GroupStackT); PTRACE_STACK_LIMIT lowers it too.
@@ -497,6 +502,375 @@ int refit_expanded(pt_context *ctx, const RefitArgs &ra)
     return PT_OK;
 }
 
+// ---- the tree built on the device (pt_build.hpp) ----------------------------------------------------------------
+constexpr size_t kDeviceBuildMinPrims = 2000000;     // option tree_build 2: scenes below this build on the host (its tree is a little better)
+constexpr int kDeviceBuildFallback = -1000;          // not an error: the caller goes on with the host build
+constexpr int kDeviceBuildMaxLevels = 2048;
+constexpr int kLargeShare = 32;                      // at most one primitive in this many is set aside as large,
+constexpr int kLargeShareMin = 8;                    // (room for the measurement knob to go down to)
+constexpr int kLargeAreaLog2 = 4;                    // and only with a box area of 2^this times the median or more
+constexpr int kDeviceBuildTopClusters = 8192;        // clusters at which the clustering rounds stop and the host builds the top of the tree
+
+// One device allocation cut into 256-byte-aligned parts: first a dry run for the size, then the same calls for the pointers.
+struct DeviceArena {
+    char *base = nullptr;
+    size_t used = 0;
+    template <class T> void take(T *&p, size_t n)
+    {
+        p = base ? reinterpret_cast<T *>(base + used) : nullptr;
+        used += (n * sizeof(T) + 255) & ~(size_t)255;
+    }
+};
+
+// The scene as pt_set_spheres / pt_set_meshes left it, every mesh object flattened (RayTracingShader.compute:236-240 applied
+// once instead of per ray), as a four-wide tree made on the device.  The host touches the objects and the spheres, never a
+// triangle.  Leaves the context exactly as the host build of a flat scene does, minus the two-child tree.
+int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int nS = (int)ctx->spheres.size();
+    const size_t nO = ctx->objects.size();
+    const size_t nP = (size_t)nS + nt;
+    if (nP < 2 || nP >= (1u << 27)) return kDeviceBuildFallback;
+    const int n = (int)nP;
+    int rc;
+    // ---- inputs: geometry and matrices stay on the device for refits, the rest lives in the arena
+    std::vector<int4> otab(nO + 1);
+    for (size_t o = 0; o < nO; o++) otab[o] = make_int4((int)obj_first_tri[o], ctx->objects[o].indices_offset, 0, 0);
+    otab[nO] = make_int4((int)nt, 0, 0, 0);
+    std::vector<float> mats(nO * 16);
+    for (size_t o = 0; o < nO; o++) std::memcpy(&mats[o * 16], ctx->objects[o].local_to_world, 64);
+    std::vector<float4> smat((size_t)nS * 4);
+    for (int i = 0; i < nS; i++) {
+        const PtSphere &sp = ctx->spheres[i];
+        smat[i * 4 + 0] = make_float4(sp.position[0], sp.position[1], sp.position[2], sp.radius);
+        smat[i * 4 + 1] = make_float4(sp.albedo[0], sp.albedo[1], sp.albedo[2], sp.smoothness);
+        smat[i * 4 + 2] = make_float4(sp.specular[0], sp.specular[1], sp.specular[2], 0.0f);
+        smat[i * 4 + 3] = make_float4(sp.emission[0], sp.emission[1], sp.emission[2], 0.0f);
+    }
+    free_dev(ctx->d_inst); free_dev(ctx->d_objects); free_dev(ctx->d_indices); free_dev(ctx->d_nodes); free_dev(ctx->d_nodes8);
+    free_dev(ctx->d_nodes4); free_dev(ctx->d_prims); free_dev(ctx->d_slot_src); free_dev(ctx->d_prim_box); free_dev(ctx->d_node_box);
+    free_dev(ctx->d_slot_clip); free_dev(ctx->d_build_matrices); free_dev(ctx->d_level_nodes);
+    free_expanded(ctx);
+    ctx->expanded = false; ctx->device_built = false; ctx->refit_ready = false;
+    ctx->n_nodes = ctx->n_nodes4 = 0; ctx->n_inst = 0; ctx->inst_sig.clear(); ctx->inst_node_cap = ctx->inst_rec_cap = 0;
+    if ((rc = upload(ctx, ctx->d_vertices, ctx->vertices.data(), ctx->vertices.size() * sizeof(float)))) return rc;
+    if ((rc = upload(ctx, ctx->d_matrices, mats.data(), mats.size() * sizeof(float)))) return rc;
+    if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
+
+    struct Parts {
+        int32_t *indices; int4 *objects; uint32_t *bounds;
+        int4 *src; float4 *prims; float *box;
+        uint64_t *keys[2]; uint32_t *vals[2];
+        float4 *cl_lo[2], *cl_hi[2]; int32_t *nn; uint64_t *flags, *offs, *totals;
+        int2 *bn_child; float4 *bn_lo, *bn_hi;
+        int32_t *items[2], *stacked[2]; int4 *kids;
+        uint4 *nodes4; uint32_t *slot_prim, *slot_prim_dfs; int32_t *stack_need;
+        float4 *large_lo, *large_hi; uint32_t *hist;
+        int2 *below, *place;
+        char *temp;
+    } d{};
+    size_t sort_bytes = 0, scan_bytes = 0;
+    {
+        uint64_t *k = nullptr; uint32_t *v = nullptr;
+        PT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, (size_t)n, 0u, 63u, ctx->stream));
+        PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, k, k, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
+    }
+    const size_t temp_bytes = std::max(sort_bytes, scan_bytes) + 256;
+    const size_t n_bounds = 6 * (nO + 1);
+    auto layout = [&](DeviceArena &a) {
+        a.take(d.indices, ctx->indices.size()); a.take(d.objects, nO + 1); a.take(d.bounds, n_bounds);
+        a.take(d.src, nP); a.take(d.prims, nP * 3); a.take(d.box, nP * 6);
+        for (int k = 0; k < 2; k++) { a.take(d.keys[k], nP); a.take(d.vals[k], nP); a.take(d.cl_lo[k], nP); a.take(d.cl_hi[k], nP); a.take(d.items[k], nP); a.take(d.stacked[k], nP); }
+        a.take(d.nn, nP); a.take(d.flags, nP); a.take(d.offs, nP); a.take(d.totals, 32);
+        a.take(d.bn_child, nP); a.take(d.bn_lo, nP); a.take(d.bn_hi, nP);
+        a.take(d.kids, nP); a.take(d.nodes4, nP * 4); a.take(d.slot_prim, nP + 1); a.take(d.slot_prim_dfs, nP + 1); a.take(d.stack_need, 64);
+        a.take(d.below, nP); a.take(d.place, nP);
+        a.take(d.large_lo, nP / kLargeShareMin + 1); a.take(d.large_hi, nP / kLargeShareMin + 1); a.take(d.hist, 256);
+        a.take(d.temp, temp_bytes);
+    };
+    DeviceArena arena;
+    layout(arena);
+    const size_t arena_bytes = arena.used;
+    char *arena_mem = nullptr;
+    PT_HIP(ctx, dev_malloc((void **)&arena_mem, arena_bytes));
+    struct Release { char *p; ~Release() { if (p) (void)dev_free(p); } } release{arena_mem};
+    arena = DeviceArena(); arena.base = arena_mem;
+    layout(arena);
+    const auto grid = [](size_t count) { return dim3((unsigned)((count + kBuildBlock - 1) / kBuildBlock)); };
+    hipStream_t st = ctx->stream;
+
+    // ---- bounds
+    std::vector<uint32_t> bounds(n_bounds);
+    for (size_t b = 0; b <= nO; b++)
+        for (int k = 0; k < 3; k++) { bounds[b * 6 + k] = 0xffffffffu; bounds[b * 6 + 3 + k] = 0u; }
+    PT_HIP(ctx, hipMemcpyAsync(d.indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d.objects, otab.data(), otab.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemcpyAsync(d.bounds, bounds.data(), n_bounds * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemsetAsync(d.stack_need, 0, 64 * sizeof(int32_t), st));
+    BuildScene bs;
+    bs.vertices = ctx->d_vertices; bs.indices = d.indices; bs.matrices = ctx->d_matrices; bs.objects = d.objects; bs.spheres = ctx->d_sphere_mat;
+    bs.n_objects = (int32_t)nO; bs.n_spheres = nS; bs.n_tris = (int32_t)nt;
+    if (nt) hipLaunchKernelGGL(build_bounds_kernel, grid(nt), dim3(kBuildBlock), 0, st, bs, d.bounds + 6 * nO, d.bounds);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(bounds.data(), d.bounds, n_bounds * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    const auto t_bounds = std::chrono::steady_clock::now();
+    float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    ctx->object_box.assign(nO, Aabb{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}});
+    for (size_t b = 0; b <= nO; b++)
+        for (int k = 0; k < 3; k++) {
+            if (bounds[b * 6 + k] == 0xffffffffu) continue;            // nothing finite on this axis
+            const float l = ordered_float(bounds[b * 6 + k]), h = ordered_float(bounds[b * 6 + 3 + k]);
+            if (b < nO) { ctx->object_box[b].lo[k] = l; ctx->object_box[b].hi[k] = h; } else { slo[k] = l; shi[k] = h; }
+        }
+    for (int k = 0; k < 3; k++) { ctx->spheres_lo[k] = INFINITY; ctx->spheres_hi[k] = -INFINITY; }
+    for (int i = 0; i < nS; i++) {
+        const PtSphere &sp = ctx->spheres[i];
+        const float r = std::fabs(sp.radius);
+        for (int k = 0; k < 3; k++) {
+            const float l = sp.position[k] - r, h = sp.position[k] + r;
+            if (std::fabs(l) < kHugeCoord) { slo[k] = std::min(slo[k], l); ctx->spheres_lo[k] = std::min(ctx->spheres_lo[k], l); }
+            if (std::fabs(h) < kHugeCoord) { shi[k] = std::max(shi[k], h); ctx->spheres_hi[k] = std::max(ctx->spheres_hi[k], h); }
+        }
+    }
+    // the paddings: the same figures, for the same reasons, as the host build's (rebuild_scene)
+    float diag = std::sqrt((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
+    if (!std::isfinite(diag)) diag = 0.0f;
+    float pad = 3e-6f * diag + 1e-6f;
+    if (const char *env = std::getenv("PTRACE_PAD_SCALE")) pad *= std::max(0.0f, (float)std::atof(env));
+    const float reach = std::max(2.0f * diag, ctx->sphere_reach_request);
+    const float sphere_slack2 = 8.0f * 5.9604645e-8f * reach * reach;
+    ctx->sphere_reach = reach;
+    for (int k = 0; k < 3; k++) { ctx->scene_lo[k] = slo[k] <= shi[k] ? slo[k] : 0.0f; ctx->scene_hi[k] = slo[k] <= shi[k] ? shi[k] : 0.0f; }
+
+    // ---- records and padded boxes per primitive, Morton order
+    hipLaunchKernelGGL(build_prims_kernel, grid(nP), dim3(kBuildBlock), 0, st, bs, d.src, d.prims);
+    RefitArgs ra;
+    ra.slot_src = d.src; ra.vertices = ctx->d_vertices; ra.matrices = ctx->d_matrices; ra.prims = d.prims; ra.prim_box = d.box;
+    ra.slot_clip = nullptr; ra.build_matrices = nullptr; ra.nodes4 = nullptr; ra.nodes8 = nullptr; ra.node_box = nullptr; ra.level_nodes = nullptr;
+    ra.pad = pad; ra.reach = reach; ra.sphere_slack2 = sphere_slack2; ra.n_prims = n;
+    hipLaunchKernelGGL(refit_prims_kernel, grid(nP), dim3(kRefitBlock), 0, st, ra);
+    MortonGrid mg;
+    for (int k = 0; k < 3; k++) {
+        mg.lo[k] = ctx->scene_lo[k];
+        const float ext = ctx->scene_hi[k] - ctx->scene_lo[k];
+        mg.scale[k] = ext > 0.0f && std::isfinite(ext) ? 2097152.0f / ext : 0.0f;
+    }
+    hipLaunchKernelGGL(build_morton_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.box, n, mg, d.keys[0], d.vals[0]);
+    PT_HIP(ctx, hipGetLastError());
+    {
+        size_t bytes = temp_bytes;
+        PT_HIP(ctx, rocprim::radix_sort_pairs(d.temp, bytes, d.keys[0], d.keys[1], d.vals[0], d.vals[1], (size_t)n, 0u, 63u, st));
+    }
+    // ---- which primitives are large: at least kLargeAreaRatio times the median box area, and at most one in kLargeShare
+    int n_large = 0;
+    {
+        std::vector<uint32_t> hist(256, 0);
+        PT_HIP(ctx, hipMemsetAsync(d.hist, 0, 256 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(area_histogram_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.box, n, d.hist);
+        PT_HIP(ctx, hipMemcpyAsync(hist.data(), d.hist, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        int median = 0;
+        for (size_t seen = 0; median < 255 && (seen += hist[(size_t)median]) * 2 < nP; median++) {}
+        int large_exponent = 256;
+        size_t above = 0;
+        int share = kLargeShare, ratio = kLargeAreaLog2;
+        if (const char *env = std::getenv("PTRACE_BUILD_LARGE")) std::sscanf(env, "%d,%d", &share, &ratio);                           // measurement knob: "share,log2 ratio"; share 0 = none
+        if (share > 0 && share < kLargeShareMin) share = kLargeShareMin;
+        for (int e = 255; e >= median + ratio && e > 0 && share > 0; e--) {
+            if ((above + hist[(size_t)e]) * (size_t)share > nP) break;
+            above += hist[(size_t)e]; large_exponent = e;
+        }
+        n_large = (int)above;
+        if (n_large >= n - 1) { n_large = 0; large_exponent = 256; }
+        if (n_large) {
+            hipLaunchKernelGGL(large_flag_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, (uint32_t)large_exponent, d.flags);
+            size_t bytes = temp_bytes;
+            PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), st));
+            hipLaunchKernelGGL(ploc_init_split_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.flags, d.offs, d.cl_lo[0], d.cl_hi[0], d.large_lo, d.large_hi);
+        } else {
+            hipLaunchKernelGGL(ploc_init_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.cl_lo[0], d.cl_hi[0]);
+        }
+    }
+    PT_HIP(ctx, hipGetLastError());
+    std::chrono::steady_clock::time_point t_sorted;
+    if (std::getenv("PTRACE_BUILD_TIMING")) PT_HIP(ctx, hipStreamSynchronize(st));
+    t_sorted = std::chrono::steady_clock::now();
+
+    // ---- the two-child tree: clusters merge with their best neighbour until one is left
+    TwoChildTree tree{d.bn_child, d.bn_lo, d.bn_hi};
+    int c = n - n_large, made = 0, rounds = 0, cur = 0;
+    int radius = kPlocRadius;
+    if (const char *env = std::getenv("PTRACE_PLOC_RADIUS")) radius = std::max(1, std::min(kPlocRadiusMax, std::atoi(env)));      // measurement knob
+    float lambda = 0.0f;
+    if (const char *env = std::getenv("PTRACE_PLOC_LAMBDA")) lambda = (float)std::atof(env);                                          // measurement knob
+    int top_clusters = kDeviceBuildTopClusters;
+    if (const char *env = std::getenv("PTRACE_BUILD_TOP")) top_clusters = std::max(1, std::atoi(env));                               // measurement knob
+    while (c > top_clusters) {
+        hipLaunchKernelGGL(ploc_nn_kernel, grid((size_t)c), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], c, d.nn, radius, lambda);
+        hipLaunchKernelGGL(ploc_flag_kernel, grid((size_t)c), dim3(kBuildBlock), 0, st, d.nn, c, d.flags);
+        size_t bytes = temp_bytes;
+        PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)c, rocprim::plus<uint64_t>(), st));
+        hipLaunchKernelGGL(ploc_merge_kernel, grid((size_t)c), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], d.nn, d.flags, d.offs, c, made, tree,
+                           d.cl_lo[cur ^ 1], d.cl_hi[cur ^ 1], d.totals);
+        uint64_t tot = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&tot, d.totals, sizeof tot, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        const int kept = (int)(uint32_t)tot, merged = (int)(tot >> 32);
+        if (merged < 1 || kept != c - merged) return fail(ctx, PT_ERR_HIP, "device tree build: a clustering round merged nothing");
+        c = kept; made += merged; cur ^= 1; rounds++;
+    }
+    int32_t root = made - 1;
+    if (c + n_large > 1) {
+        // ---- the top of the tree: the host's binned-SAH builder over the clusters that are left (a few thousand boxes, a
+        // millisecond or two).  Clustering is at its best near the leaves, where a good partner is always close by in the sorted
+        // order; near the root it pairs whatever is left, and every ray pays for overlap there.
+        std::vector<float4> clo((size_t)c + (size_t)n_large), chi((size_t)c + (size_t)n_large);
+        PT_HIP(ctx, hipMemcpyAsync(clo.data(), d.cl_lo[cur], (size_t)c * sizeof(float4), hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(chi.data(), d.cl_hi[cur], (size_t)c * sizeof(float4), hipMemcpyDeviceToHost, st));
+        if (n_large) {
+            PT_HIP(ctx, hipMemcpyAsync(clo.data() + c, d.large_lo, (size_t)n_large * sizeof(float4), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipMemcpyAsync(chi.data() + c, d.large_hi, (size_t)n_large * sizeof(float4), hipMemcpyDeviceToHost, st));
+        }
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        c += n_large;
+        std::vector<Aabb> cbox((size_t)c);
+        for (int i = 0; i < c; i++) cbox[(size_t)i] = Aabb{{clo[(size_t)i].x, clo[(size_t)i].y, clo[(size_t)i].z}, {chi[(size_t)i].x, chi[(size_t)i].y, chi[(size_t)i].z}};
+        const BvhResult top = build_bvh(cbox, 1, 0, 1.0f);
+        const size_t T = top.nodes.size();
+        if (T != (size_t)c - 1) return fail(ctx, PT_ERR_HIP, "device tree build: the top-level tree is incomplete");
+        std::vector<int2> tchild(T); std::vector<float4> tlo(T), thi(T);
+        std::vector<int32_t> below(T);
+        const auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+        for (size_t j = T; j-- > 0;) {                       // children come after their parents
+            const BvhNode &nd = top.nodes[j];
+            int32_t ref[2], cnt[2];
+            const int32_t link[2] = {nd.left, nd.right};
+            for (int k = 0; k < 2; k++) {
+                if (link[k] >= 0) { ref[k] = made + link[k]; cnt[k] = below[(size_t)link[k]]; }
+                else {
+                    const uint32_t enc = (uint32_t)~link[k];
+                    if (enc & 7u) return fail(ctx, PT_ERR_HIP, "device tree build: a top-level leaf of several clusters");
+                    const uint32_t cl = top.order[enc >> 3];
+                    ref[k] = bits(clo[cl].w); cnt[k] = bits(chi[cl].w);
+                }
+            }
+            below[j] = cnt[0] + cnt[1];
+            float bf; std::memcpy(&bf, &below[j], 4);
+            tchild[j] = make_int2(ref[0], ref[1]);
+            tlo[j] = make_float4(std::min(nd.llo[0], nd.rlo[0]), std::min(nd.llo[1], nd.rlo[1]), std::min(nd.llo[2], nd.rlo[2]), 0.0f);
+            thi[j] = make_float4(std::max(nd.lhi[0], nd.rhi[0]), std::max(nd.lhi[1], nd.rhi[1]), std::max(nd.lhi[2], nd.rhi[2]), bf);
+        }
+        PT_HIP(ctx, hipMemcpyAsync(d.bn_child + made, tchild.data(), T * sizeof(int2), hipMemcpyHostToDevice, st));
+        PT_HIP(ctx, hipMemcpyAsync(d.bn_lo + made, tlo.data(), T * sizeof(float4), hipMemcpyHostToDevice, st));
+        PT_HIP(ctx, hipMemcpyAsync(d.bn_hi + made, thi.data(), T * sizeof(float4), hipMemcpyHostToDevice, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));               // the vectors go out of scope
+        root = made;
+        made += (int)T;
+    }
+    if (made != n - 1) return fail(ctx, PT_ERR_HIP, "device tree build: the two-child tree is incomplete");
+    {
+        int bottom = 32;
+        if (const char *env = std::getenv("PTRACE_BUILD_BOTTOM")) bottom = std::atoi(env);                                          // measurement knob: 0, 8, 16, 32, 64
+        const dim3 g((unsigned)((2 * (size_t)made + 63) / 64));
+        if (bottom >= 64) hipLaunchKernelGGL(bottom_rebuild_kernel<64>, g, dim3(64), 0, st, tree, made, d.box);
+        else if (bottom >= 32) hipLaunchKernelGGL(bottom_rebuild_kernel<32>, g, dim3(64), 0, st, tree, made, d.box);
+        else if (bottom >= 16) hipLaunchKernelGGL(bottom_rebuild_kernel<16>, g, dim3(64), 0, st, tree, made, d.box);
+        else if (bottom >= 8) hipLaunchKernelGGL(bottom_rebuild_kernel<8>, g, dim3(64), 0, st, tree, made, d.box);
+    }
+    if (std::getenv("PTRACE_BUILD_TIMING")) PT_HIP(ctx, hipStreamSynchronize(st));
+    const auto t_tree = std::chrono::steady_clock::now();
+
+    // ---- four children per node, one level per round from the root; level l's nodes are level_base[l] .. + level_count[l]
+    std::vector<int> level_base, level_count;
+    {
+        const int32_t zero = 0;
+        PT_HIP(ctx, hipMemcpyAsync(d.items[0], &root, 4, hipMemcpyHostToDevice, st));
+        PT_HIP(ctx, hipMemcpyAsync(d.stacked[0], &zero, 4, hipMemcpyHostToDevice, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+    }
+    int items = 1, nodes_done = 0, recs_done = 0, side = 0;
+    bool open_pairs = false;
+    if (const char *env = std::getenv("PTRACE_BUILD_OPEN_PAIRS")) open_pairs = std::atoi(env) != 0;                                  // measurement knob
+    while (items > 0) {
+        if ((int)level_base.size() >= kDeviceBuildMaxLevels) return kDeviceBuildFallback;
+        CollapseArgs ca;
+        ca.tree = tree; ca.items = d.items[side]; ca.stacked = d.stacked[side]; ca.n_items = items;
+        ca.passes = open_pairs ? 2 : 1;
+        ca.level_base = nodes_done; ca.next_base = nodes_done + items; ca.rec_base = recs_done; ca.zero_rec = n;
+        ca.kids = d.kids; ca.counts = d.flags; ca.offs = d.offs; ca.items_next = d.items[side ^ 1]; ca.stacked_next = d.stacked[side ^ 1];
+        ca.nodes4 = d.nodes4; ca.slot_prim = d.slot_prim; ca.stack_need = d.stack_need; ca.totals = d.totals;
+        hipLaunchKernelGGL(collapse_pick_kernel, grid((size_t)items), dim3(kBuildBlock), 0, st, ca);
+        size_t bytes = temp_bytes;
+        PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)items, rocprim::plus<uint64_t>(), st));
+        hipLaunchKernelGGL(collapse_emit_kernel, grid((size_t)items), dim3(kBuildBlock), 0, st, ca);
+        uint64_t tot = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&tot, d.totals, sizeof tot, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        level_base.push_back(nodes_done); level_count.push_back(items);
+        nodes_done += items; recs_done += (int)(tot >> 32);
+        items = (int)(uint32_t)tot; side ^= 1;
+        if ((size_t)nodes_done + (size_t)items > nP) return fail(ctx, PT_ERR_HIP, "device tree build: more nodes than primitives");
+    }
+    if (recs_done != n) return fail(ctx, PT_ERR_HIP, "device tree build: the collapse lost a primitive");
+    int32_t stack_need = 0;
+    PT_HIP(ctx, hipMemcpyAsync(&stack_need, d.stack_need, 4, hipMemcpyDeviceToHost, st));
+    PT_HIP(ctx, hipStreamSynchronize(st));
+    if (stack_need > ctx->stack_limit) return kDeviceBuildFallback;
+    const int n4 = nodes_done, levels = (int)level_base.size();
+    const auto t_wide = std::chrono::steady_clock::now();
+
+    // ---- the arrays the kernels read: records in tree order, nodes, boxes from the leaves up
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_nodes4, (size_t)n4 * sizeof(Bvh4Node)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_prims, (nP + 1) * 3 * sizeof(float4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_slot_src, (nP + 1) * sizeof(int4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_prim_box, (nP + 1) * 6 * sizeof(float)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_node_box, (size_t)n4 * 6 * sizeof(float)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_level_nodes, (size_t)n4 * sizeof(int32_t)));
+    ctx->level_first.assign(1, 0);
+    for (int l = levels - 1; l >= 0; l--) ctx->level_first.push_back(ctx->level_first.back() + level_count[l]);       // deepest level first
+    {
+        ReorderArgs ro;
+        ro.nodes_in = d.nodes4; ro.slot_prim_in = d.slot_prim; ro.below = d.below; ro.place = d.place; ro.nodes_out = ctx->d_nodes4; ro.slot_prim_out = d.slot_prim_dfs;
+        for (int l = levels - 1; l >= 0; l--) {
+            ro.first = level_base[l]; ro.count = level_count[l]; ro.level_nodes_out = nullptr;
+            hipLaunchKernelGGL(reorder_count_kernel, grid((size_t)ro.count), dim3(kBuildBlock), 0, st, ro);
+        }
+        PT_HIP(ctx, hipMemsetAsync(d.place, 0, sizeof(int2), st));             // the root: node 0, record 0
+        for (int l = 0; l < levels; l++) {
+            ro.first = level_base[l]; ro.count = level_count[l]; ro.level_nodes_out = ctx->d_level_nodes + ctx->level_first[(size_t)(levels - 1 - l)];
+            hipLaunchKernelGGL(reorder_place_kernel, grid((size_t)ro.count), dim3(kBuildBlock), 0, st, ro);
+        }
+    }
+    hipLaunchKernelGGL(build_gather_kernel, grid(nP + 1), dim3(kBuildBlock), 0, st, d.slot_prim_dfs, n, d.src, d.prims, d.box, ctx->d_slot_src, ctx->d_prims, ctx->d_prim_box);
+    ra.slot_src = ctx->d_slot_src; ra.prims = ctx->d_prims; ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
+    for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
+        const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
+        hipLaunchKernelGGL(refit_nodes_kernel, grid((size_t)count), dim3(kRefitBlock), 0, st, ra, first, count);
+    }
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipStreamSynchronize(st));               // the arena goes when this returns
+    ctx->device_built = true;
+    ctx->refit_ready = ctx->refit != 0 && nO > 0;
+    ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
+    ctx->walk8 = false; ctx->n_nodes8 = 0; ctx->stack_need8 = 0;
+    ctx->n_nodes4 = n4; ctx->n_nodes = n4;                // no two-child tree: n_nodes only says "there is a tree"
+    ctx->n_prims = n; ctx->n_slots = n; ctx->n_top_records = n; ctx->n_spheres = nS;
+    ctx->stack_need4 = stack_need;
+    ctx->stats.bvh_nodes = n4; ctx->stats.bvh_prims = n; ctx->stats.bvh_depth = levels;
+    ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("PTRACE_BUILD_TIMING")) {
+        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "scene build on the device: %d primitives (%d large), %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; upload + bounds %.1f ms, "
+                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", n, n_large, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
+                     ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()));
+    }
+    ctx->scene_dirty = false;
+    ctx->bvh2_stale = false;
+    return PT_OK;
+}
+
 // Flatten meshes to world space (RayTracingShader.compute:236-240 applied once
 // instead of per ray), box every primitive, build the BVH, upload.
 int rebuild_scene(pt_context *ctx)
@@ -525,6 +899,14 @@ int rebuild_scene(pt_context *ctx)
     if (ctx->instancing && !ctx->flatten_once && ctx->bvh_width == 4) groups = find_instances(ctx->objects, ctx->indices, ctx->vertices, obj_group, obj_base, expand);
 #endif
     ctx->flatten_once = false;
+#if !defined(PT_NODES_SOA) && !defined(PT_NODES_3LOAD)
+    if (groups.empty() && ctx->bvh_width == 4 &&
+        (ctx->tree_build == 1 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
+        const int rc = build_scene_on_device(ctx, obj_first_tri, nt);
+        if (rc != kDeviceBuildFallback) return rc;
+    }
+#endif
+    ctx->device_built = false;
     std::vector<Aabb> group_bounds(groups.size()); std::vector<char> group_bounds_done(groups.size(), 0);
     {
         size_t n_flat = 0;
@@ -1212,7 +1594,7 @@ int rebuild_scene(pt_context *ctx);
 int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
 {
     if (tree_width(ctx) == 2 && (ctx->bvh2_stale || ctx->n_inst)) ctx->scene_dirty = true;   // the two-child tree is flat and never refitted
-    if (ctx->expanded && ctx->bvh_width != 4) ctx->scene_dirty = true;                        // another width: a host build of the flattened scene
+    if ((ctx->expanded || ctx->device_built) && ctx->bvh_width != 4) ctx->scene_dirty = true;  // another width: a host build of the flattened scene
     for (int pass = 0; pass < 2; pass++) {
         if (ctx->scene_dirty) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1438,6 +1820,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : std::atoi(env) == 8 ? 8 : 4;
     if (const char *env = std::getenv("PTRACE_BLOCK_ORDER")) ctx->block_order = std::atoi(env) != 0;
     if (const char *env = std::getenv("PTRACE_FAST_INTRINSICS")) ctx->fast_intrinsics = std::atoi(env) != 0;
+    if (const char *env = std::getenv("PTRACE_TREE_BUILD")) ctx->tree_build = std::max(0, std::min(2, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_SPLIT")) ctx->split_budget = std::max(0.0f, std::min(4.0f, (float)std::atof(env)));
     if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = ctx->vote_shade_few = std::max(1, std::min(64, std::atoi(env)));
@@ -2092,6 +2475,12 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: instancing must be 0, 1 or 2");
         if (ctx->instancing != value) ctx->scene_dirty = true;
         ctx->instancing = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "tree_build") == 0) {
+        if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: tree_build must be 0, 1 or 2");
+        if (ctx->tree_build != value) ctx->scene_dirty = true;
+        ctx->tree_build = value;
         return PT_OK;
     }
     if (std::strcmp(name, "split_percent") == 0) {
