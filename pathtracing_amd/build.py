@@ -41,7 +41,7 @@ def _run(cmd, cwd):
 
 def build_ptrace(force=False):
     out = os.path.join(CSRC, "libptrace.so")
-    srcs = [os.path.join(CSRC, f) for f in ("ptrace_api.hip", "bvh.cpp", "bvh.hpp", "pt_device.hpp", "pt_wavefront.hpp", "pt_pool.hpp", "pt_screen.hpp", "pt_refit.hpp", "pt_build.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ptrace_api.hip", "bvh.cpp", "bvh.hpp", "pt_device.hpp", "pt_wavefront.hpp", "pt_pool.hpp", "pt_screen.hpp", "pt_refit.hpp", "pt_build.hpp", "pt_build_sah.hpp")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("ptrace.h", "ptrace_fmath.h")]
     if force or _newer(out, srcs):
         _run([HIPCC] + HIP_FLAGS + ["-o", out, "ptrace_api.hip", "bvh.cpp", "-lpthread"], CSRC)

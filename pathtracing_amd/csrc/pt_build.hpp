@@ -182,52 +182,6 @@ __global__ __launch_bounds__(kBuildBlock) void ploc_init_kernel(const uint32_t *
     hi[i] = make_float4(b[3], b[4], b[5], __int_as_float(1));
 }
 
-// ---- large primitives.  A floor slab among finely tessellated columns sits in the sorted order between clusters a
-// hundredth of its size; whichever of them it finally merges with, the union spans the slab and overlaps everything the
-// slab covers.  A top-down builder separates such a primitive from the small ones near the root.  So primitives whose box
-// area is far above the scene's median stay out of the clustering and go to the host's SAH builder as clusters of their own,
-// together with the clusters the rounds end with.
-// hist[e]: primitives whose box half-area has the biased exponent e (bits 23..30 of the float).
-__global__ __launch_bounds__(kBuildBlock) void area_histogram_kernel(const float *box, int n, uint32_t *hist)
-{
-    __shared__ uint32_t local[256];
-    local[threadIdx.x] = 0;
-    __syncthreads();
-    const int p = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (p < n) {
-        const float *b = box + (size_t)p * 6;
-        const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
-        atomicAdd(&local[(__float_as_uint(ex * ey + ey * ez + ez * ex) >> 23) & 255u], 1u);
-    }
-    __syncthreads();
-    if (local[threadIdx.x]) atomicAdd(hist + threadIdx.x, local[threadIdx.x]);
-}
-
-// flags[i] for the primitive at sorted place i: 1 (low word) if it takes part in the clustering, 1 << 32 if it is large.
-__global__ __launch_bounds__(kBuildBlock) void large_flag_kernel(const uint32_t *sorted, const float *box, int n, uint32_t large_exponent, uint64_t *flags)
-{
-    const int i = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (i >= n) return;
-    const float *b = box + (size_t)sorted[i] * 6;
-    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
-    const bool large = ((__float_as_uint(ex * ey + ey * ez + ez * ex) >> 23) & 255u) >= large_exponent;
-    flags[i] = large ? (uint64_t)1 << 32 : (uint64_t)1;
-}
-
-// The clusters the rounds start from (the small primitives, in sorted order) and the large ones set aside.
-__global__ __launch_bounds__(kBuildBlock) void ploc_init_split_kernel(const uint32_t *sorted, const float *box, int n, const uint64_t *flags, const uint64_t *offs,
-                                                                      float4 *lo, float4 *hi, float4 *large_lo, float4 *large_hi)
-{
-    const int i = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t p = sorted[i];
-    const float *b = box + (size_t)p * 6;
-    const float4 l = make_float4(b[0], b[1], b[2], __int_as_float(~(int32_t)p)), h = make_float4(b[3], b[4], b[5], __int_as_float(1));
-    const uint64_t o = offs[i];
-    if (flags[i] >> 32) { large_lo[o >> 32] = l; large_hi[o >> 32] = h; }
-    else { lo[(uint32_t)o] = l; hi[(uint32_t)o] = h; }
-}
-
 // nn[i]: the cluster within kPlocRadius places of i whose union with i has the smallest area; of equals, the first.
 __global__ __launch_bounds__(kBuildBlock) void ploc_nn_kernel(const float4 *lo, const float4 *hi, int c, int32_t *nn, const int R, const float lambda)
 {
@@ -304,20 +258,20 @@ __global__ __launch_bounds__(kBuildBlock) void ploc_merge_kernel(const float4 *l
     lo_out[dst] = a; hi_out[dst] = b;
 }
 
-// ---- the bottom of the tree, again.  Clustering is greedy and blind to what it leaves behind: its first rounds pair
-// primitives off by what happens to be mutual, leftovers join as singles, and the groups of a few dozen primitives that
-// result - L-shapes, strips, threes and fives - fill the slots of four-wide nodes badly and overlap their neighbours.
-// Measured on the 262 k-triangle scene, handing the host's SAH builder everything above clusters of four primitives still
-// left the tree with 8 % more node visits per ray than the host's own.  So every subtree of at most M primitives (whose
-// parent has more) is rebuilt from its primitives' boxes by one thread, top-down: a set of more than kExhaustivePrims is
-// split where a sweep along the best axis finds the smallest area-weighted count (exact SAH, no bins: the sets are small),
-// a smaller one into the best of ALL its two-part splits (127 candidates for eight primitives).  The subtree keeps its
-// node numbers and its root, so nothing above it changes.
-constexpr int kExhaustivePrims = 8;
+// ---- the bottom of the tree, again.  Clustering pairs primitives off in its first rounds by what happens to be mutual, and
+// what is left over joins as singles: subtrees of three, five, seven primitives whose inner topology is whatever order the
+// merges came in.  Every subtree of at most kBottomPrims primitives (whose parent has more) is rebuilt from its primitives'
+// boxes by one thread, top-down: each set goes into the two parts of smallest area-weighted size, found by trying ALL
+// two-part splits (127 for eight primitives).  The subtree keeps its node numbers and its root, so nothing above it changes.
+// (Worth 2-5 % of the rays per second on the 70 k-triangle mesh, nothing on the 262 k-triangle hall.  The same with a sweep
+// along three axes for subtrees of up to 64 primitives changed the hall's node visits per ray from 16.73 to 16.69 and took
+// twenty times as long as the rest of the build: the clusters' insides are not where clustering loses to the host's
+// top-down SAH.)
+constexpr int kBottomPrims = 8;
 
-template <int M>
 __global__ __launch_bounds__(64) void bottom_rebuild_kernel(const TwoChildTree tree, int n_nodes, const float *prim_box)
 {
+    constexpr int M = kBottomPrims;
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * n_nodes) return;
     const int parent = t >> 1;
@@ -345,93 +299,45 @@ __global__ __launch_bounds__(64) void bottom_rebuild_kernel(const TwoChildTree t
     float lo[M][3], hi[M][3];
     for (int k = 0; k < m; k++)
         for (int ax = 0; ax < 3; ax++) { lo[k][ax] = prim_box[(size_t)prim[k] * 6 + ax]; hi[k][ax] = prim_box[(size_t)prim[k] * 6 + 3 + ax]; }
-    // order[]: the primitives (as indices into prim / lo / hi); a range of it is a set.  work[]: the ranges still to be split.
-    uint8_t order[M];
-    for (int k = 0; k < m; k++) order[k] = (uint8_t)k;
-    struct Range { uint8_t begin, end; int32_t node; };
-    Range work[M];
-    int n_work = 0, next_id = 0;
-    work[n_work++] = Range{0, (uint8_t)m, ids[next_id++]};
-    float sweep[M];
-    float area[1 << kExhaustivePrims];
-    while (n_work) {
-        const Range r = work[--n_work];
-        const int b = r.begin, e = r.end, k = e - b;
-        float bl[3] = {PT_INF, PT_INF, PT_INF}, bh[3] = {-PT_INF, -PT_INF, -PT_INF};
-        for (int i = b; i < e; i++)
-            for (int ax = 0; ax < 3; ax++) { bl[ax] = fminf(bl[ax], lo[order[i]][ax]); bh[ax] = fmaxf(bh[ax], hi[order[i]][ax]); }
-        int left = 1;                // primitives of the left part, which end up first in the range
-        if (k == 2) {
-            left = 1;
-        } else if (k <= kExhaustivePrims) {
-            const int full = (1 << k) - 1;
-            for (int s = 1; s <= full; s++) {
-                float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
-                for (int q = 0; q < k; q++)
-                    if ((s >> q) & 1)
-                        for (int ax = 0; ax < 3; ax++) { l[ax] = fminf(l[ax], lo[order[b + q]][ax]); h[ax] = fmaxf(h[ax], hi[order[b + q]][ax]); }
-                const float ex = h[0] - l[0], ey = h[1] - l[1], ez = h[2] - l[2];
-                area[s] = ex * ey + ey * ez + ez * ex;
-            }
-            int best = 1; float best_cost = PT_INF;
-            for (int sub = (full - 1) & full; sub; sub = (sub - 1) & full) {      // every split; the part with the first member is `sub`
-                if (!(sub & 1)) continue;
-                const int rest = full ^ sub;
-                const float c = area[sub] * (float)__popc(sub) + area[rest] * (float)__popc(rest);
-                if (c < best_cost || (c == best_cost && sub < best)) { best_cost = c; best = sub; }
-            }
-            // members of `best` first, order kept otherwise
-            uint8_t tmp[kExhaustivePrims];
-            int nl = 0, nr = 0;
-            left = __popc(best);
-            for (int q = 0; q < k; q++) { if ((best >> q) & 1) tmp[nl++] = order[b + q]; }
-            for (int q = 0; q < k; q++) { if (!((best >> q) & 1)) tmp[left + nr++] = order[b + q]; }
-            for (int q = 0; q < k; q++) order[b + q] = tmp[q];
-        } else {
-            int best_axis = -1, best_pos = 0; float best_cost = PT_INF;
-            for (int ax = 0; ax < 3; ax++) {
-                // insertion sort of the range by centre along ax (ties keep their order), then the two sweeps
-                for (int i = b + 1; i < e; i++) {
-                    const uint8_t v = order[i];
-                    const float key = lo[v][ax] + hi[v][ax];
-                    int j = i - 1;
-                    while (j >= b && lo[order[j]][ax] + hi[order[j]][ax] > key) { order[j + 1] = order[j]; j--; }
-                    order[j + 1] = v;
-                }
-                float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
-                for (int i = e - 1; i > b; i--) {            // sweep[i]: area of the box of order[i .. e)
-                    for (int a2 = 0; a2 < 3; a2++) { l[a2] = fminf(l[a2], lo[order[i]][a2]); h[a2] = fmaxf(h[a2], hi[order[i]][a2]); }
-                    const float ex = h[0] - l[0], ey = h[1] - l[1], ez = h[2] - l[2];
-                    sweep[i] = ex * ey + ey * ez + ez * ex;
-                }
-                for (int a2 = 0; a2 < 3; a2++) { l[a2] = PT_INF; h[a2] = -PT_INF; }
-                for (int i = b; i < e - 1; i++) {            // split after position i
-                    for (int a2 = 0; a2 < 3; a2++) { l[a2] = fminf(l[a2], lo[order[i]][a2]); h[a2] = fmaxf(h[a2], hi[order[i]][a2]); }
-                    const float ex = h[0] - l[0], ey = h[1] - l[1], ez = h[2] - l[2];
-                    const float c = (ex * ey + ey * ez + ez * ex) * (float)(i - b + 1) + sweep[i + 1] * (float)(e - i - 1);
-                    if (c < best_cost) { best_cost = c; best_axis = ax; best_pos = i - b + 1; }
-                }
-            }
-            if (best_axis < 0) { best_axis = 2; best_pos = k / 2; }          // no finite cost: halve the range as it lies
-            if (best_axis != 2)                                              // the range lies sorted along the last axis tried
-                for (int i = b + 1; i < e; i++) {
-                    const uint8_t v = order[i];
-                    const float key = lo[v][best_axis] + hi[v][best_axis];
-                    int j = i - 1;
-                    while (j >= b && lo[order[j]][best_axis] + hi[order[j]][best_axis] > key) { order[j + 1] = order[j]; j--; }
-                    order[j + 1] = v;
-                }
-            left = best_pos;
+    // half the surface area of every subset's box, and - for the nodes written below - the box itself on demand
+    float area[1 << M];
+    const int full = (1 << m) - 1;
+    for (int s = 1; s <= full; s++) {
+        float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
+        for (int k = 0; k < m; k++)
+            if ((s >> k) & 1)
+                for (int ax = 0; ax < 3; ax++) { l[ax] = fminf(l[ax], lo[k][ax]); h[ax] = fmaxf(h[ax], hi[k][ax]); }
+        const float ex = h[0] - l[0], ey = h[1] - l[1], ez = h[2] - l[2];
+        area[s] = ex * ey + ey * ez + ez * ex;
+    }
+    // top-down: sets[] holds the subsets still to be split, each with the node number it was given
+    int sets[M]; int32_t set_node[M];
+    int next_id = 0, n_sets = 0;
+    sets[n_sets] = full; set_node[n_sets++] = ids[next_id++];
+    while (n_sets) {
+        const int s = sets[--n_sets];
+        const int32_t node = set_node[n_sets];
+        const int low = s & -s;
+        int best = low; float best_cost = PT_INF;
+        for (int sub = (s - 1) & s; sub; sub = (sub - 1) & s) {      // every split of s; the part with s's first member is `sub`
+            if (!(sub & low)) continue;
+            const int rest = s ^ sub;
+            const float c = area[sub] * (float)__popc(sub) + area[rest] * (float)__popc(rest);
+            if (c < best_cost || (c == best_cost && sub < best)) { best_cost = c; best = sub; }
         }
+        const int part[2] = {best, s ^ best};
         int32_t ref[2];
-        const int part_begin[2] = {b, b + left}, part_end[2] = {b + left, e};
-        for (int c = 0; c < 2; c++) {
-            if (part_end[c] - part_begin[c] == 1) ref[c] = ~prim[order[part_begin[c]]];
-            else { ref[c] = ids[next_id]; work[n_work++] = Range{(uint8_t)part_begin[c], (uint8_t)part_end[c], ids[next_id++]}; }
+        for (int k = 0; k < 2; k++) {
+            if (__popc(part[k]) == 1) ref[k] = ~prim[__ffs(part[k]) - 1];
+            else { ref[k] = ids[next_id]; sets[n_sets] = part[k]; set_node[n_sets++] = ids[next_id++]; }
         }
-        tree.child[r.node] = make_int2(ref[0], ref[1]);
-        tree.lo[r.node] = make_float4(bl[0], bl[1], bl[2], __int_as_float(r.node));
-        tree.hi[r.node] = make_float4(bh[0], bh[1], bh[2], __int_as_float(k));
+        float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
+        for (int k = 0; k < m; k++)
+            if ((s >> k) & 1)
+                for (int ax = 0; ax < 3; ax++) { l[ax] = fminf(l[ax], lo[k][ax]); h[ax] = fmaxf(h[ax], hi[k][ax]); }
+        tree.child[node] = make_int2(ref[0], ref[1]);
+        tree.lo[node] = make_float4(l[0], l[1], l[2], __int_as_float(node));
+        tree.hi[node] = make_float4(h[0], h[1], h[2], __int_as_float(__popc(s)));
     }
 }
 
@@ -441,7 +347,8 @@ struct CollapseArgs {
     const int32_t *items;         // this level's nodes, as two-child node numbers; four-wide node level_base + t comes from items[t]
     const int32_t *stacked;       // stack entries a ray holds when it enters each
     int32_t n_items, level_base, next_base, rec_base, zero_rec;
-    int32_t passes;               // 2: pairs of primitives are opened into free slots; 1: they stay leaves of two records
+    int32_t passes;               // 2: pairs of primitives may be opened into free slots; 1: they stay leaves of two records
+    const float *prim_box;        // 6 floats per primitive
     int4 *kids;                   // per item, the up to four references chosen
     uint64_t *counts;             // per item: inner children | records << 32
     const uint64_t *offs;         // exclusive prefix sums of counts
@@ -461,8 +368,10 @@ __device__ __forceinline__ float half_area(const TwoChildTree &t, int32_t ref)
 }
 
 // The children of one four-wide node: the two-child node's two, then - while a slot is free - the inner child of largest
-// area opened into its two (bvh.cpp's rule); subtrees of two primitives are opened last, and only into free slots: left
-// closed they become one leaf of two records.
+// area opened into its two (bvh.cpp's rule).  A subtree of two primitives becomes one leaf of two records unless a slot is
+// free AND the two boxes' areas add up to less than the pair's (the host builder's rule for ending at a leaf, bvh.cpp:133:
+// testing both, 2 A, against one more visit and each on its own, A + A_left + A_right): a leaf visit costs a wave a round
+// of its leaf phase whether the leaf holds one record or two, and most pairs are the two halves of a quad.
 __global__ __launch_bounds__(kBuildBlock) void collapse_pick_kernel(const CollapseArgs a)
 {
     const int t = blockIdx.x * kBuildBlock + threadIdx.x;
@@ -479,6 +388,13 @@ __global__ __launch_bounds__(kBuildBlock) void collapse_pick_kernel(const Collap
                 const int cnt = prims_below(a.tree, kids[k]);
                 if (pass == 0 ? cnt > 2 : cnt == 2) {
                     const float ar = half_area(a.tree, kids[k]);
+                    if (pass == 1) {
+                        const int2 two = a.tree.child[kids[k]];
+                        const float *p = a.prim_box + (size_t)~two.x * 6, *q = a.prim_box + (size_t)~two.y * 6;
+                        const float pa = (p[3] - p[0]) * (p[4] - p[1]) + (p[4] - p[1]) * (p[5] - p[2]) + (p[5] - p[2]) * (p[3] - p[0]);
+                        const float qa = (q[3] - q[0]) * (q[4] - q[1]) + (q[4] - q[1]) * (q[5] - q[2]) + (q[5] - q[2]) * (q[3] - q[0]);
+                        if (!(pa + qa < ar)) continue;
+                    }
                     if (ar > best_area) { best_area = ar; best = k; }
                 }
             }
@@ -586,6 +502,28 @@ __global__ __launch_bounds__(kBuildBlock) void reorder_place_kernel(const Reorde
     }
     *reinterpret_cast<Bvh4Node *>(a.nodes_out + (size_t)me.x * 4) = nd;
     a.level_nodes_out[t] = me.x;
+}
+
+// Measurement (PTRACE_BUILD_TIMING): the surface-area cost of the four-wide tree as it lies on the device - the sum over
+// nodes of box area / root area, which is the expected number of node visits of a ray that crosses the root's box at
+// random.  One partial sum per block.
+__global__ __launch_bounds__(kBuildBlock) void tree_cost_kernel(const float *node_box, int n_nodes, float *partial)
+{
+    __shared__ float sums[kBuildBlock];
+    const int i = blockIdx.x * kBuildBlock + threadIdx.x;
+    float a = 0.0f;
+    if (i < n_nodes) {
+        const float *b = node_box + (size_t)i * 6, *r = node_box;
+        const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2], rx = r[3] - r[0], ry = r[4] - r[1], rz = r[5] - r[2];
+        a = (ex * ey + ey * ez + ez * ex) / (rx * ry + ry * rz + rz * rx);
+    }
+    sums[threadIdx.x] = a;
+    __syncthreads();
+    for (int d = kBuildBlock / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) sums[threadIdx.x] += sums[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sums[0];
 }
 
 // The records in tree order: what build_prims_kernel and refit_prims_kernel made per primitive, moved to its slot.

@@ -1,0 +1,351 @@
+// The two-child tree of the device build, top-down by the surface-area heuristic - the host builder's algorithm (bvh.cpp:
+// binned SAH) laid out for the GPU.
+//
+// Clustering from the leaves up (pt_build.hpp, ploc_*) is quick, but greedy: on the 262 k-triangle hall its tree costs
+// 12 % more node visits per ray than the host's, and neither rebuilding the insides of its clusters nor handing their tops
+// to the host's builder recovers more than a quarter of that - which primitives end up together is decided badly, at every
+// scale.  Splitting from the root down decides exactly that, with the whole range in view.
+//
+//   upper levels, one pass per level over all primitives (they lie in Morton order, and a stable partition keeps every
+//   node's primitives one contiguous, still Morton-ordered range):
+//     sah_bin_kernel        every primitive of a node with more than kSahSmall adds its box to one of 16 bins per axis of
+//                           its node (by its centre's place in the node's box); a block first collects, in LDS, what goes
+//                           to the node of its first primitive - near the root that is everything
+//     sah_split_kernel      per node: the cheapest of the 45 bin boundaries, area(left) n_left + area(right) n_right; the
+//                           two children get numbers, boxes (exact: unions of bins) and ranges
+//     sah_next_kernel       children with more than kSahSmall primitives form the next level, the others go on a list
+//     sah_side_kernel, scan, sah_partition_kernel   left primitives to the front of the node's range, order kept
+//   lower levels: sah_small_kernel, one wave per listed node, builds the whole subtree of its <= kSahSmall primitives in LDS
+//   by the same rule - no global traffic but the primitives in and the nodes out.
+// Min, max and integer add commute exactly, so the bins - and the tree - do not depend on the order the atomics land in.
+#pragma once
+
+#include "pt_build.hpp"
+
+namespace ptrace {
+
+constexpr int kSahBins = 16;           // 32, the host builder's count, gave 1-2 % MORE node visits per ray here (15.79 against 15.62 on the 262 k-triangle hall)
+constexpr int kSahBinWords = 3 * kSahBins * 7;       // per node: [axis][bin] (lo.xyz as ordered words, hi.xyz, count)
+constexpr int kSahSmall = 128;
+
+struct SahRange {
+    float lo[3]; int32_t begin;        // box of the range's primitives; first place in the primitive array
+    float hi[3]; int32_t count;
+    int32_t node, parent, side, pad;   // its number in the two-child tree; where the link to it sits
+};
+static_assert(sizeof(SahRange) == 48, "SahRange layout");
+
+__device__ __forceinline__ int sah_bin(float lo, float hi, float range_lo, float scale)
+{
+    const float x = (0.5f * lo + 0.5f * hi - range_lo) * scale;
+    return x >= 0.0f ? min(kSahBins - 1, (int)x) : 0;
+}
+__device__ __forceinline__ float sah_scale(float lo, float hi)
+{
+    const float ext = hi - lo;
+    return ext > 0.0f && ext < PT_INF ? (float)kSahBins / ext : 0.0f;
+}
+
+// The box of all primitives: 6 ordered words, lo from 0xffffffff, hi from 0.
+__global__ __launch_bounds__(kBuildBlock) void sah_bounds_kernel(const float4 *p_lo, const float4 *p_hi, int n, uint32_t *bounds)
+{
+    int i = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (i >= n) i = n - 1;
+    const float4 a = p_lo[i], b = p_hi[i];
+    const float l[3] = {a.x, a.y, a.z}, h[3] = {b.x, b.y, b.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float wl = wave_min(l[k]), wh = wave_max(h[k]);
+        if ((threadIdx.x & 63) == 0) { atomicMin(bounds + k, ordered_bits(wl)); atomicMax(bounds + 3 + k, ordered_bits(wh)); }
+    }
+}
+
+__global__ __launch_bounds__(kBuildBlock) void sah_fill_kernel(uint32_t *bins, size_t words)
+{
+    const size_t w = (size_t)blockIdx.x * kBuildBlock + threadIdx.x;
+    if (w >= words) return;
+    const uint32_t k = (uint32_t)(w % 7);
+    bins[w] = k < 3 ? 0xffffffffu : 0u;
+}
+
+// seg[i]: this level's node of the primitive at place i (an index into `act`), or -1 once it lies in a listed node.
+__global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, uint32_t *bins)
+{
+    __shared__ uint32_t local[kSahBinWords];
+    const int first = blockIdx.x * kBuildBlock;
+    const int home = seg[first];
+    for (int w = threadIdx.x; w < kSahBinWords; w += kBuildBlock) local[w] = (w % 7) < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    const int i = first + threadIdx.x;
+    if (i < n) {
+        const int a = seg[i];
+        if (a >= 0) {
+            const SahRange r = act[a];
+            const float4 pl = p_lo[i], ph = p_hi[i];
+            const float l[3] = {pl.x, pl.y, pl.z}, h[3] = {ph.x, ph.y, ph.z};
+            uint32_t ol[3], oh[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { ol[k] = ordered_bits(l[k]); oh[k] = ordered_bits(h[k]); }
+            uint32_t *dst = a == home ? local : bins + (size_t)a * kSahBinWords;
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                uint32_t *w = dst + (ax * kSahBins + sah_bin(l[ax], h[ax], r.lo[ax], sah_scale(r.lo[ax], r.hi[ax]))) * 7;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { atomicMin(w + k, ol[k]); atomicMax(w + 3 + k, oh[k]); }
+                atomicAdd(w + 6, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (home < 0) return;
+    uint32_t *dst = bins + (size_t)home * kSahBinWords;
+    for (int w = threadIdx.x; w < kSahBinWords; w += kBuildBlock) {
+        const uint32_t v = local[w], k = (uint32_t)(w % 7);
+        if (k < 3) { if (v != 0xffffffffu) atomicMin(dst + w, v); }
+        else if (v) { if (k < 6) atomicMax(dst + w, v); else atomicAdd(dst + w, v); }
+    }
+}
+
+__device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+struct SahBox { float l[3], h[3]; uint32_t n; };
+__device__ __forceinline__ void sah_box_reset(SahBox &b) { for (int k = 0; k < 3; k++) { b.l[k] = PT_INF; b.h[k] = -PT_INF; } b.n = 0; }
+__device__ __forceinline__ void sah_box_add(SahBox &b, const uint32_t *w)
+{
+    if (!w[6]) return;
+    for (int k = 0; k < 3; k++) { b.l[k] = fminf(b.l[k], ordered_to_float(w[k])); b.h[k] = fmaxf(b.h[k], ordered_to_float(w[3 + k])); }
+    b.n += w[6];
+}
+__device__ __forceinline__ float sah_box_cost(const SahBox &b)
+{
+    const float ex = b.h[0] - b.l[0], ey = b.h[1] - b.l[1], ez = b.h[2] - b.l[2];
+    return (ex * ey + ey * ez + ez * ex) * (float)b.n;
+}
+
+// split[a] = (axis or -1, last bin of the left part, primitives on the left, 0).  Candidates 2 a and 2 a + 1 are the
+// children; flags says which of them form the next level (low word) and which go on the list (high word).
+__global__ __launch_bounds__(kBuildBlock) void sah_split_kernel(const SahRange *act, int n_act, const uint32_t *bins, int node_base, TwoChildTree tree, int4 *split,
+                                                                SahRange *cand, uint64_t *flags)
+{
+    const int a = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (a >= n_act) return;
+    const SahRange r = act[a];
+    const uint32_t *nb = bins + (size_t)a * kSahBinWords;
+    int best_axis = -1, best_bin = 0; float best_cost = PT_INF;
+    for (int ax = 0; ax < 3; ax++) {
+        float right_cost[kSahBins];          // right_cost[s]: bins s + 1 .. 15
+        SahBox acc; sah_box_reset(acc);
+        for (int b = kSahBins - 1; b >= 1; b--) { sah_box_add(acc, nb + (ax * kSahBins + b) * 7); right_cost[b - 1] = acc.n ? sah_box_cost(acc) : PT_INF; }
+        sah_box_reset(acc);
+        for (int s = 0; s < kSahBins - 1; s++) {
+            sah_box_add(acc, nb + (ax * kSahBins + s) * 7);
+            if (!acc.n || !(right_cost[s] < PT_INF)) continue;
+            const float c = sah_box_cost(acc) + right_cost[s];
+            if (c < best_cost) { best_cost = c; best_axis = ax; best_bin = s; }
+        }
+    }
+    SahBox left, right;
+    if (best_axis >= 0) {
+        sah_box_reset(left); sah_box_reset(right);
+        for (int b = 0; b < kSahBins; b++) sah_box_add(b <= best_bin ? left : right, nb + (best_axis * kSahBins + b) * 7);
+    } else {
+        // every centre in one bin on every axis: halve the range as it lies; the children's boxes are the parent's (they
+        // hold what is in them, which is all a box has to do)
+        for (int k = 0; k < 3; k++) { left.l[k] = right.l[k] = r.lo[k]; left.h[k] = right.h[k] = r.hi[k]; }
+        left.n = (uint32_t)r.count / 2; right.n = (uint32_t)r.count - left.n;
+    }
+    split[a] = make_int4(best_axis, best_bin, (int)left.n, 0);
+    for (int s = 0; s < 2; s++) {
+        const SahBox &b = s ? right : left;
+        SahRange c;
+        for (int k = 0; k < 3; k++) { c.lo[k] = b.l[k]; c.hi[k] = b.h[k]; }
+        c.begin = r.begin + (s ? (int)left.n : 0); c.count = (int)b.n;
+        c.node = node_base + 2 * a + s; c.parent = r.node; c.side = s; c.pad = 0;
+        cand[2 * a + s] = c;
+        flags[2 * a + s] = c.count > kSahSmall ? (uint64_t)1 : (uint64_t)1 << 32;
+    }
+    tree.child[r.node] = make_int2(node_base + 2 * a, node_base + 2 * a + 1);
+    tree.lo[r.node] = make_float4(r.lo[0], r.lo[1], r.lo[2], __int_as_float(r.node));
+    tree.hi[r.node] = make_float4(r.hi[0], r.hi[1], r.hi[2], __int_as_float(r.count));
+}
+
+// offs = exclusive prefix sums of flags.  slot[c]: candidate c's index in the next level, or -1.
+__global__ __launch_bounds__(kBuildBlock) void sah_next_kernel(const SahRange *cand, int n_cand, const uint64_t *flags, const uint64_t *offs, SahRange *act_next, SahRange *small,
+                                                               int small_base, int32_t *slot, uint64_t *totals)
+{
+    const int c = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (c >= n_cand) return;
+    const uint64_t f = flags[c], o = offs[c];
+    if (c == n_cand - 1) totals[0] = o + f;
+    if ((uint32_t)f) { act_next[(uint32_t)o] = cand[c]; slot[c] = (int32_t)(uint32_t)o; }
+    else { small[small_base + (int)(o >> 32)] = cand[c]; slot[c] = -1; }
+}
+
+__global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, const int4 *split, uint32_t *left)
+{
+    const int i = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (i >= n) return;
+    const int a = seg[i];
+    uint32_t l = 0;
+    if (a >= 0) {
+        const int4 sp = split[a];
+        if (sp.x < 0) l = i - act[a].begin < sp.z;
+        else {
+            const float rl = act[a].lo[sp.x], rh = act[a].hi[sp.x];
+            const float4 pl = p_lo[i], ph = p_hi[i];
+            const float lo = sp.x == 0 ? pl.x : sp.x == 1 ? pl.y : pl.z, hi = sp.x == 0 ? ph.x : sp.x == 1 ? ph.y : ph.z;
+            l = sah_bin(lo, hi, rl, sah_scale(rl, rh)) <= sp.y;
+        }
+    }
+    left[i] = l;
+}
+
+// rank = exclusive prefix sums of left.  Within each node's range: the left primitives first, the right ones after, both in
+// the order they had; everything else stays where it is.
+__global__ __launch_bounds__(kBuildBlock) void sah_partition_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, const int4 *split,
+                                                                    const uint32_t *left, const uint32_t *rank, const int32_t *slot, float4 *q_lo, float4 *q_hi, int32_t *seg_out)
+{
+    const int i = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (i >= n) return;
+    const int a = seg[i];
+    int pos = i, s = -1;
+    if (a >= 0) {
+        const int begin = act[a].begin, n_left = split[a].z;
+        const int before = (int)(rank[i] - rank[begin]);          // left primitives of the node before this one
+        const bool l = left[i] != 0;
+        pos = l ? begin + before : begin + n_left + (i - begin - before);
+        s = slot[2 * a + (l ? 0 : 1)];
+    }
+    q_lo[pos] = p_lo[i]; q_hi[pos] = p_hi[i]; seg_out[pos] = s;
+}
+
+// extra[j]: node numbers listed node j needs beyond its own (a subtree of k primitives has k - 1 nodes).
+__global__ __launch_bounds__(kBuildBlock) void sah_extra_kernel(const SahRange *small, int n_small, uint64_t *extra)
+{
+    const int j = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (j < n_small) extra[j] = (uint64_t)max(0, small[j].count - 2);
+}
+
+// One wave per listed node: its subtree, built in LDS.  order[] holds the node's primitives (as indices into the arrays
+// loaded below) so that every range still to be split is a stretch of it; the stack holds those ranges.
+__global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, const uint64_t *extra_offs, int extra_base, const float4 *p_lo, const float4 *p_hi, TwoChildTree tree)
+{
+    constexpr int S = kSahSmall;
+    __shared__ float blo[3][S], bhi[3][S];
+    __shared__ int32_t ref[S];
+    __shared__ uint8_t order[2][S];
+    __shared__ uint32_t bins[kSahBinWords];
+    __shared__ uint16_t stack_begin[S], stack_end[S];
+    __shared__ int32_t stack_node[S];
+    static_assert(S <= 256, "order[] holds bytes");
+    const int lane = threadIdx.x;
+    const SahRange r = small[blockIdx.x];
+    const int count = r.count;
+    if (count <= 0 || count > S) return;
+    if (count == 1) {                        // a leaf: the link that names this node names the primitive instead
+        if (lane == 0) reinterpret_cast<int32_t *>(tree.child + r.parent)[r.side] = __float_as_int(p_lo[r.begin].w);
+        return;
+    }
+    for (int i = lane; i < count; i += 64) {
+        const float4 a = p_lo[r.begin + i], b = p_hi[r.begin + i];
+        blo[0][i] = a.x; blo[1][i] = a.y; blo[2][i] = a.z; bhi[0][i] = b.x; bhi[1][i] = b.y; bhi[2][i] = b.z;
+        ref[i] = __float_as_int(a.w);
+        order[0][i] = (uint8_t)i;
+    }
+    int next_node = extra_base + (int)extra_offs[blockIdx.x];
+    int sp = 1;
+    if (lane == 0) { stack_begin[0] = 0; stack_end[0] = (uint16_t)count; stack_node[0] = r.node; }
+    __syncthreads();
+    while (sp > 0) {
+        sp--;
+        const int b = stack_begin[sp], e = stack_end[sp], node = stack_node[sp], k = e - b;
+        __syncthreads();                     // everyone has read the entry before it is overwritten
+        float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
+        for (int i = b + lane; i < e; i += 64) {
+            const int p = order[0][i];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) { l[ax] = fminf(l[ax], blo[ax][p]); h[ax] = fmaxf(h[ax], bhi[ax][p]); }
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) { l[ax] = wave_min(l[ax]); h[ax] = wave_max(h[ax]); }
+        int n_left = 1;
+        if (k > 2) {
+            for (int w = lane; w < kSahBinWords; w += 64) bins[w] = (w % 7) < 3 ? 0xffffffffu : 0u;
+            __syncthreads();
+            float scale[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) scale[ax] = sah_scale(l[ax], h[ax]);
+            for (int i = b + lane; i < e; i += 64) {
+                const int p = order[0][i];
+                uint32_t ol[3], oh[3];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) { ol[ax] = ordered_bits(blo[ax][p]); oh[ax] = ordered_bits(bhi[ax][p]); }
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    uint32_t *w = bins + (ax * kSahBins + sah_bin(blo[ax][p], bhi[ax][p], l[ax], scale[ax])) * 7;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { atomicMin(w + q, ol[q]); atomicMax(w + 3 + q, oh[q]); }
+                    atomicAdd(w + 6, 1u);
+                }
+            }
+            __syncthreads();
+            // candidate c = axis * (kSahBins - 1) + s: the split after bin s of that axis; the lanes share them out
+            float best = PT_INF; int best_cand = 3 * (kSahBins - 1); uint32_t my_left = 0;
+            for (int c = lane; c < 3 * (kSahBins - 1); c += 64) {
+                const int ax = c / (kSahBins - 1), s = c % (kSahBins - 1);
+                SahBox lb, rb; sah_box_reset(lb); sah_box_reset(rb);
+                for (int q = 0; q < kSahBins; q++) sah_box_add(q <= s ? lb : rb, bins + (ax * kSahBins + q) * 7);
+                if (!lb.n || !rb.n) continue;
+                const float cost = sah_box_cost(lb) + sah_box_cost(rb);
+                if (cost < best) { best = cost; best_cand = c; my_left = lb.n; }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float oc = __shfl_xor(best, d, 64); const int ocand = __shfl_xor(best_cand, d, 64); const uint32_t oleft = __shfl_xor(my_left, d, 64);
+                if (oc < best || (oc == best && ocand < best_cand)) { best = oc; best_cand = ocand; my_left = oleft; }
+            }
+            if (best < PT_INF) {
+                n_left = (int)my_left;
+                const int ax = best_cand / (kSahBins - 1), s = best_cand % (kSahBins - 1);
+                int done_left = 0, done_right = 0;
+                for (int base = b; base < e; base += 64) {
+                    const int i = base + lane;
+                    const bool valid = i < e;
+                    const int p = valid ? order[0][i] : 0;
+                    const bool left = valid && sah_bin(blo[ax][p], bhi[ax][p], l[ax], scale[ax]) <= s;
+                    const unsigned long long ml = __ballot(left), mr = __ballot(valid && !left);
+                    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+                    if (left) order[1][b + done_left + __popcll(ml & below)] = (uint8_t)p;
+                    else if (valid) order[1][b + n_left + done_right + __popcll(mr & below)] = (uint8_t)p;
+                    done_left += __popcll(ml); done_right += __popcll(mr);
+                }
+                __syncthreads();
+                for (int i = b + lane; i < e; i += 64) order[0][i] = order[1][i];
+            } else {
+                n_left = k / 2;              // all centres in one bin on every axis: halve the range as it lies
+            }
+            __syncthreads();
+        }
+        // the node, and what is still to be split
+        if (lane == 0) {
+            int32_t link[2];
+            const int part_begin[2] = {b, b + n_left}, part_end[2] = {b + n_left, e};
+            for (int s = 0; s < 2; s++) {
+                if (part_end[s] - part_begin[s] == 1) link[s] = ref[order[0][part_begin[s]]];
+                else {
+                    link[s] = next_node;
+                    stack_begin[sp] = (uint16_t)part_begin[s]; stack_end[sp] = (uint16_t)part_end[s]; stack_node[sp] = next_node;
+                    sp++; next_node++;
+                }
+            }
+            tree.child[node] = make_int2(link[0], link[1]);
+            tree.lo[node] = make_float4(l[0], l[1], l[2], __int_as_float(node));
+            tree.hi[node] = make_float4(h[0], h[1], h[2], __int_as_float(k));
+        }
+        // the other lanes follow lane 0's bookkeeping
+        sp = __shfl(sp, 0, 64); next_node = __shfl(next_node, 0, 64);
+        __syncthreads();
+    }
+}
+
+}  // namespace ptrace

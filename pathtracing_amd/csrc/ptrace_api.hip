@@ -22,6 +22,7 @@
 #include "pt_screen.hpp"
 #include "pt_refit.hpp"
 #include "pt_build.hpp"
+#include "pt_build_sah.hpp"
 
 using namespace ptrace;
 
@@ -119,8 +120,10 @@ struct pt_context {
     int32_t *d_exp_top_levels = nullptr;
     std::vector<int> exp_top_first;
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
-    // option "tree_build": 0 the host's binned-SAH builder, 1 the device builder (pt_build.hpp) for whatever is not a copy of a
-    // shared mesh, 2 (default) the device builder for scenes of kDeviceBuildMinPrims primitives or more
+    // option "tree_build": 0 the host's binned-SAH builder; 1 the device builder (pt_build.hpp; top-down SAH, pt_build_sah.hpp) for
+    // whatever is not a copy of a shared mesh; 2 (default) the device builder for scenes of kDeviceBuildMinPrims primitives or
+    // more; 3 the device builder with its two-child tree made by clustering - a quarter of the build time, a fifth fewer rays
+    // per second
     int tree_build = 2;
     bool device_built = false;        // the last build ran on the device: a four-wide tree only, like `expanded`
     float4 *d_inst = nullptr;         // SceneDev::inst
@@ -506,9 +509,6 @@ int refit_expanded(pt_context *ctx, const RefitArgs &ra)
 constexpr size_t kDeviceBuildMinPrims = 2000000;     // option tree_build 2: scenes below this build on the host (its tree is a little better)
 constexpr int kDeviceBuildFallback = -1000;          // not an error: the caller goes on with the host build
 constexpr int kDeviceBuildMaxLevels = 2048;
-constexpr int kLargeShare = 32;                      // at most one primitive in this many is set aside as large,
-constexpr int kLargeShareMin = 8;                    // (room for the measurement knob to go down to)
-constexpr int kLargeAreaLog2 = 4;                    // and only with a box area of 2^this times the median or more
 constexpr int kDeviceBuildTopClusters = 8192;        // clusters at which the clustering rounds stop and the host builds the top of the tree
 
 // One device allocation cut into 256-byte-aligned parts: first a dry run for the size, then the same calls for the pointers.
@@ -566,8 +566,8 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         int2 *bn_child; float4 *bn_lo, *bn_hi;
         int32_t *items[2], *stacked[2]; int4 *kids;
         uint4 *nodes4; uint32_t *slot_prim, *slot_prim_dfs; int32_t *stack_need;
-        float4 *large_lo, *large_hi; uint32_t *hist;
         int2 *below, *place;
+        SahRange *act[2], *cand, *small; int32_t *slot; int4 *split; uint32_t *bins;
         char *temp;
     } d{};
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -576,17 +576,25 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         PT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, (size_t)n, 0u, 63u, ctx->stream));
         PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, k, k, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
     }
-    const size_t temp_bytes = std::max(sort_bytes, scan_bytes) + 256;
+    size_t scan32_bytes = 0;
+    {
+        uint32_t *v = nullptr;
+        PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan32_bytes, v, v, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+    }
+    const size_t temp_bytes = std::max(std::max(sort_bytes, scan_bytes), scan32_bytes) + 256;
+    const size_t sah_nodes = nP / kSahSmall + 2;          // nodes of more than kSahSmall primitives one level can hold
+    const size_t tree_cap = 2 * nP + 1024;                // two-child node numbers (the top-down build leaves gaps in them)
     const size_t n_bounds = 6 * (nO + 1);
     auto layout = [&](DeviceArena &a) {
         a.take(d.indices, ctx->indices.size()); a.take(d.objects, nO + 1); a.take(d.bounds, n_bounds);
         a.take(d.src, nP); a.take(d.prims, nP * 3); a.take(d.box, nP * 6);
         for (int k = 0; k < 2; k++) { a.take(d.keys[k], nP); a.take(d.vals[k], nP); a.take(d.cl_lo[k], nP); a.take(d.cl_hi[k], nP); a.take(d.items[k], nP); a.take(d.stacked[k], nP); }
         a.take(d.nn, nP); a.take(d.flags, nP); a.take(d.offs, nP); a.take(d.totals, 32);
-        a.take(d.bn_child, nP); a.take(d.bn_lo, nP); a.take(d.bn_hi, nP);
+        a.take(d.bn_child, tree_cap); a.take(d.bn_lo, tree_cap); a.take(d.bn_hi, tree_cap);
         a.take(d.kids, nP); a.take(d.nodes4, nP * 4); a.take(d.slot_prim, nP + 1); a.take(d.slot_prim_dfs, nP + 1); a.take(d.stack_need, 64);
         a.take(d.below, nP); a.take(d.place, nP);
-        a.take(d.large_lo, nP / kLargeShareMin + 1); a.take(d.large_hi, nP / kLargeShareMin + 1); a.take(d.hist, 256);
+        a.take(d.act[0], sah_nodes); a.take(d.act[1], sah_nodes); a.take(d.cand, 2 * sah_nodes); a.take(d.small, nP); a.take(d.slot, 2 * sah_nodes); a.take(d.split, sah_nodes);
+        a.take(d.bins, sah_nodes * kSahBinWords);
         a.take(d.temp, temp_bytes);
     };
     DeviceArena arena;
@@ -604,7 +612,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     std::vector<uint32_t> bounds(n_bounds);
     for (size_t b = 0; b <= nO; b++)
         for (int k = 0; k < 3; k++) { bounds[b * 6 + k] = 0xffffffffu; bounds[b * 6 + 3 + k] = 0u; }
-    PT_HIP(ctx, hipMemcpyAsync(d.indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!ctx->indices.empty()) PT_HIP(ctx, hipMemcpyAsync(d.indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d.objects, otab.data(), otab.size() * sizeof(int4), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d.bounds, bounds.data(), n_bounds * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemsetAsync(d.stack_need, 0, 64 * sizeof(int32_t), st));
@@ -663,44 +671,77 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         size_t bytes = temp_bytes;
         PT_HIP(ctx, rocprim::radix_sort_pairs(d.temp, bytes, d.keys[0], d.keys[1], d.vals[0], d.vals[1], (size_t)n, 0u, 63u, st));
     }
-    // ---- which primitives are large: at least kLargeAreaRatio times the median box area, and at most one in kLargeShare
-    int n_large = 0;
-    {
-        std::vector<uint32_t> hist(256, 0);
-        PT_HIP(ctx, hipMemsetAsync(d.hist, 0, 256 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(area_histogram_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.box, n, d.hist);
-        PT_HIP(ctx, hipMemcpyAsync(hist.data(), d.hist, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PT_HIP(ctx, hipStreamSynchronize(st));
-        int median = 0;
-        for (size_t seen = 0; median < 255 && (seen += hist[(size_t)median]) * 2 < nP; median++) {}
-        int large_exponent = 256;
-        size_t above = 0;
-        int share = kLargeShare, ratio = kLargeAreaLog2;
-        if (const char *env = std::getenv("PTRACE_BUILD_LARGE")) std::sscanf(env, "%d,%d", &share, &ratio);                           // measurement knob: "share,log2 ratio"; share 0 = none
-        if (share > 0 && share < kLargeShareMin) share = kLargeShareMin;
-        for (int e = 255; e >= median + ratio && e > 0 && share > 0; e--) {
-            if ((above + hist[(size_t)e]) * (size_t)share > nP) break;
-            above += hist[(size_t)e]; large_exponent = e;
-        }
-        n_large = (int)above;
-        if (n_large >= n - 1) { n_large = 0; large_exponent = 256; }
-        if (n_large) {
-            hipLaunchKernelGGL(large_flag_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, (uint32_t)large_exponent, d.flags);
-            size_t bytes = temp_bytes;
-            PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), st));
-            hipLaunchKernelGGL(ploc_init_split_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.flags, d.offs, d.cl_lo[0], d.cl_hi[0], d.large_lo, d.large_hi);
-        } else {
-            hipLaunchKernelGGL(ploc_init_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.cl_lo[0], d.cl_hi[0]);
-        }
-    }
+    hipLaunchKernelGGL(ploc_init_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.cl_lo[0], d.cl_hi[0]);
     PT_HIP(ctx, hipGetLastError());
     std::chrono::steady_clock::time_point t_sorted;
     if (std::getenv("PTRACE_BUILD_TIMING")) PT_HIP(ctx, hipStreamSynchronize(st));
     t_sorted = std::chrono::steady_clock::now();
 
-    // ---- the two-child tree: clusters merge with their best neighbour until one is left
     TwoChildTree tree{d.bn_child, d.bn_lo, d.bn_hi};
-    int c = n - n_large, made = 0, rounds = 0, cur = 0;
+    int made = 0, rounds = 0;
+    int32_t root = 0;
+    const bool top_down = ctx->tree_build != 3;
+    if (top_down) {
+        // ---- the two-child tree, top-down by SAH (pt_build_sah.hpp)
+        uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+        PT_HIP(ctx, hipMemcpyAsync(d.bounds, init, sizeof init, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(sah_bounds_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[0], d.cl_hi[0], n, d.bounds);
+        PT_HIP(ctx, hipMemcpyAsync(init, d.bounds, sizeof init, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemsetAsync(d.bn_hi, 0, tree_cap * sizeof(float4), st));          // numbers never given out hold no primitives
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        SahRange whole;
+        for (int k = 0; k < 3; k++) { whole.lo[k] = ordered_float(init[k]); whole.hi[k] = ordered_float(init[3 + k]); }
+        whole.begin = 0; whole.count = n; whole.node = 0; whole.parent = -1; whole.side = 0; whole.pad = 0;
+        int n_act = 0, n_small = 0, node_base = 1, cur = 0, level = 0;
+        int32_t *seg[2] = {d.items[0], d.items[1]};
+        uint32_t *left = reinterpret_cast<uint32_t *>(d.nn), *rank = reinterpret_cast<uint32_t *>(d.stacked[0]);
+        if (n > kSahSmall) {
+            PT_HIP(ctx, hipMemcpyAsync(d.act[0], &whole, sizeof whole, hipMemcpyHostToDevice, st));
+            PT_HIP(ctx, hipMemsetAsync(seg[0], 0, nP * sizeof(int32_t), st));
+            n_act = 1;
+        } else {
+            PT_HIP(ctx, hipMemcpyAsync(d.small, &whole, sizeof whole, hipMemcpyHostToDevice, st));
+            n_small = 1;
+        }
+        PT_HIP(ctx, hipStreamSynchronize(st));               // `whole` and `init` are on the stack
+        while (n_act > 0) {
+            if (level >= kDeviceBuildMaxLevels || (size_t)node_base + 2 * (size_t)n_act + nP > tree_cap) return kDeviceBuildFallback;
+            const SahRange *act = d.act[level & 1];
+            hipLaunchKernelGGL(sah_fill_kernel, grid((size_t)n_act * kSahBinWords), dim3(kBuildBlock), 0, st, d.bins, (size_t)n_act * kSahBinWords);
+            hipLaunchKernelGGL(sah_bin_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.bins);
+            hipLaunchKernelGGL(sah_split_kernel, grid((size_t)n_act), dim3(kBuildBlock), 0, st, act, n_act, d.bins, node_base, tree, d.split, d.cand, d.flags);
+            size_t bytes = temp_bytes;
+            PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)(2 * n_act), rocprim::plus<uint64_t>(), st));
+            hipLaunchKernelGGL(sah_next_kernel, grid((size_t)(2 * n_act)), dim3(kBuildBlock), 0, st, d.cand, 2 * n_act, d.flags, d.offs, d.act[(level + 1) & 1], d.small, n_small, d.slot,
+                               d.totals);
+            hipLaunchKernelGGL(sah_side_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left);
+            bytes = temp_bytes;
+            PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, left, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(sah_partition_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left, rank, d.slot, d.cl_lo[cur ^ 1],
+                               d.cl_hi[cur ^ 1], seg[cur ^ 1]);
+            uint64_t tot = 0;
+            PT_HIP(ctx, hipMemcpyAsync(&tot, d.totals, sizeof tot, hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            node_base += 2 * n_act; n_small += (int)(tot >> 32); n_act = (int)(uint32_t)tot;
+            if ((size_t)n_act > sah_nodes - 2 || (size_t)n_small > nP) return fail(ctx, PT_ERR_HIP, "device tree build: more ranges than primitives");
+            cur ^= 1; level++;
+        }
+        rounds = level;
+        hipLaunchKernelGGL(sah_extra_kernel, grid((size_t)n_small), dim3(kBuildBlock), 0, st, d.small, n_small, d.flags);
+        size_t bytes = temp_bytes;
+        PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)n_small, rocprim::plus<uint64_t>(), st));
+        uint64_t last[2] = {0, 0};
+        PT_HIP(ctx, hipMemcpyAsync(&last[0], d.flags + (n_small - 1), 8, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipMemcpyAsync(&last[1], d.offs + (n_small - 1), 8, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        const size_t numbers = (size_t)node_base + (size_t)(last[0] + last[1]);
+        if (numbers > tree_cap) return kDeviceBuildFallback;
+        hipLaunchKernelGGL(sah_small_kernel, dim3((unsigned)n_small), dim3(64), 0, st, d.small, d.offs, node_base, d.cl_lo[cur], d.cl_hi[cur], tree);
+        PT_HIP(ctx, hipGetLastError());
+        made = (int)numbers; root = 0;
+    } else {
+    // ---- the two-child tree by clustering: clusters merge with their best neighbour until few are left
+    int c = n, cur = 0;
     int radius = kPlocRadius;
     if (const char *env = std::getenv("PTRACE_PLOC_RADIUS")) radius = std::max(1, std::min(kPlocRadiusMax, std::atoi(env)));      // measurement knob
     float lambda = 0.0f;
@@ -721,20 +762,15 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         if (merged < 1 || kept != c - merged) return fail(ctx, PT_ERR_HIP, "device tree build: a clustering round merged nothing");
         c = kept; made += merged; cur ^= 1; rounds++;
     }
-    int32_t root = made - 1;
-    if (c + n_large > 1) {
+    root = made - 1;
+    if (c > 1) {
         // ---- the top of the tree: the host's binned-SAH builder over the clusters that are left (a few thousand boxes, a
         // millisecond or two).  Clustering is at its best near the leaves, where a good partner is always close by in the sorted
         // order; near the root it pairs whatever is left, and every ray pays for overlap there.
-        std::vector<float4> clo((size_t)c + (size_t)n_large), chi((size_t)c + (size_t)n_large);
+        std::vector<float4> clo((size_t)c), chi((size_t)c);
         PT_HIP(ctx, hipMemcpyAsync(clo.data(), d.cl_lo[cur], (size_t)c * sizeof(float4), hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipMemcpyAsync(chi.data(), d.cl_hi[cur], (size_t)c * sizeof(float4), hipMemcpyDeviceToHost, st));
-        if (n_large) {
-            PT_HIP(ctx, hipMemcpyAsync(clo.data() + c, d.large_lo, (size_t)n_large * sizeof(float4), hipMemcpyDeviceToHost, st));
-            PT_HIP(ctx, hipMemcpyAsync(chi.data() + c, d.large_hi, (size_t)n_large * sizeof(float4), hipMemcpyDeviceToHost, st));
-        }
         PT_HIP(ctx, hipStreamSynchronize(st));
-        c += n_large;
         std::vector<Aabb> cbox((size_t)c);
         for (int i = 0; i < c; i++) cbox[(size_t)i] = Aabb{{clo[(size_t)i].x, clo[(size_t)i].y, clo[(size_t)i].z}, {chi[(size_t)i].x, chi[(size_t)i].y, chi[(size_t)i].z}};
         const BvhResult top = build_bvh(cbox, 1, 0, 1.0f);
@@ -770,15 +806,9 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         made += (int)T;
     }
     if (made != n - 1) return fail(ctx, PT_ERR_HIP, "device tree build: the two-child tree is incomplete");
-    {
-        int bottom = 32;
-        if (const char *env = std::getenv("PTRACE_BUILD_BOTTOM")) bottom = std::atoi(env);                                          // measurement knob: 0, 8, 16, 32, 64
-        const dim3 g((unsigned)((2 * (size_t)made + 63) / 64));
-        if (bottom >= 64) hipLaunchKernelGGL(bottom_rebuild_kernel<64>, g, dim3(64), 0, st, tree, made, d.box);
-        else if (bottom >= 32) hipLaunchKernelGGL(bottom_rebuild_kernel<32>, g, dim3(64), 0, st, tree, made, d.box);
-        else if (bottom >= 16) hipLaunchKernelGGL(bottom_rebuild_kernel<16>, g, dim3(64), 0, st, tree, made, d.box);
-        else if (bottom >= 8) hipLaunchKernelGGL(bottom_rebuild_kernel<8>, g, dim3(64), 0, st, tree, made, d.box);
     }
+    if (!top_down && !std::getenv("PTRACE_BUILD_NO_BOTTOM"))                                                                         // (measurement knob)
+        hipLaunchKernelGGL(bottom_rebuild_kernel, dim3((unsigned)((2 * (size_t)made + 63) / 64)), dim3(64), 0, st, tree, made, d.box);
     if (std::getenv("PTRACE_BUILD_TIMING")) PT_HIP(ctx, hipStreamSynchronize(st));
     const auto t_tree = std::chrono::steady_clock::now();
 
@@ -791,13 +821,13 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         PT_HIP(ctx, hipStreamSynchronize(st));
     }
     int items = 1, nodes_done = 0, recs_done = 0, side = 0;
-    bool open_pairs = false;
+    bool open_pairs = true;
     if (const char *env = std::getenv("PTRACE_BUILD_OPEN_PAIRS")) open_pairs = std::atoi(env) != 0;                                  // measurement knob
     while (items > 0) {
         if ((int)level_base.size() >= kDeviceBuildMaxLevels) return kDeviceBuildFallback;
         CollapseArgs ca;
         ca.tree = tree; ca.items = d.items[side]; ca.stacked = d.stacked[side]; ca.n_items = items;
-        ca.passes = open_pairs ? 2 : 1;
+        ca.passes = open_pairs ? 2 : 1; ca.prim_box = d.box;
         ca.level_base = nodes_done; ca.next_base = nodes_done + items; ca.rec_base = recs_done; ca.zero_rec = n;
         ca.kids = d.kids; ca.counts = d.flags; ca.offs = d.offs; ca.items_next = d.items[side ^ 1]; ca.stacked_next = d.stacked[side ^ 1];
         ca.nodes4 = d.nodes4; ca.slot_prim = d.slot_prim; ca.stack_need = d.stack_need; ca.totals = d.totals;
@@ -862,8 +892,8 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "scene build on the device: %d primitives (%d large), %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; upload + bounds %.1f ms, "
-                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", n, n_large, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
+        std::fprintf(stderr, "scene build on the device: %d primitives, %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; upload + bounds %.1f ms, "
+                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", n, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
                      ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()));
     }
     ctx->scene_dirty = false;
@@ -901,7 +931,7 @@ int rebuild_scene(pt_context *ctx)
     ctx->flatten_once = false;
 #if !defined(PT_NODES_SOA) && !defined(PT_NODES_3LOAD)
     if (groups.empty() && ctx->bvh_width == 4 &&
-        (ctx->tree_build == 1 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
+        (ctx->tree_build == 1 || ctx->tree_build == 3 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
         const int rc = build_scene_on_device(ctx, obj_first_tri, nt);
         if (rc != kDeviceBuildFallback) return rc;
     }
@@ -1820,7 +1850,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if (const char *env = std::getenv("PTRACE_BVH_WIDTH")) ctx->bvh_width = std::atoi(env) == 2 ? 2 : std::atoi(env) == 8 ? 8 : 4;
     if (const char *env = std::getenv("PTRACE_BLOCK_ORDER")) ctx->block_order = std::atoi(env) != 0;
     if (const char *env = std::getenv("PTRACE_FAST_INTRINSICS")) ctx->fast_intrinsics = std::atoi(env) != 0;
-    if (const char *env = std::getenv("PTRACE_TREE_BUILD")) ctx->tree_build = std::max(0, std::min(2, std::atoi(env)));
+    if (const char *env = std::getenv("PTRACE_TREE_BUILD")) ctx->tree_build = std::max(0, std::min(3, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_SPLIT")) ctx->split_budget = std::max(0.0f, std::min(4.0f, (float)std::atof(env)));
     if (const char *env = std::getenv("PTRACE_STACK_LIMIT")) ctx->stack_limit = std::max(1, std::min(kStackLds + kStackOverflow, std::atoi(env)));
     if (const char *env = std::getenv("PTRACE_VOTE_SHADE")) ctx->vote_shade = ctx->vote_shade_few = std::max(1, std::min(64, std::atoi(env)));
@@ -1980,6 +2010,20 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     }
     }
     PT_HIP(ctx, hipGetLastError());
+    if (std::getenv("PTRACE_BUILD_TIMING") && !ctx->walk8 && ctx->n_nodes4 > 0) {
+        // node 0 is the root (of the top-level tree when copies hang below it); every node's box is fresh
+        const int nb = (ctx->n_nodes4 + kBuildBlock - 1) / kBuildBlock;
+        float *d_partial = nullptr;
+        PT_HIP(ctx, dev_malloc((void **)&d_partial, (size_t)nb * sizeof(float)));
+        hipLaunchKernelGGL(tree_cost_kernel, dim3((unsigned)nb), dim3(kBuildBlock), 0, ctx->stream, ctx->d_node_box, ctx->n_nodes4, d_partial);
+        std::vector<float> partial((size_t)nb);
+        PT_HIP(ctx, hipMemcpyAsync(partial.data(), d_partial, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)dev_free(d_partial);
+        double cost = 0.0;
+        for (float v : partial) cost += v;
+        std::fprintf(stderr, "tree after the refit: %d four-wide nodes, surface-area cost %.3f (expected node visits of a random ray through the root's box)\n", ctx->n_nodes4, cost);
+    }
     PT_HIP(ctx, hipEventRecord(ctx->ev_refit, ctx->stream));
     ctx->refit_in_flight = true;
     ctx->bvh2_stale = !ctx->walk8;
@@ -2478,7 +2522,7 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         return PT_OK;
     }
     if (std::strcmp(name, "tree_build") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: tree_build must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(ctx, PT_ERR_INVALID, "pt_set_option: tree_build must be 0, 1, 2 or 3");
         if (ctx->tree_build != value) ctx->scene_dirty = true;
         ctx->tree_build = value;
         return PT_OK;

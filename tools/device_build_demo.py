@@ -1,4 +1,4 @@
-"""The tree built on the device (option "tree_build" 1) against the host's (0) on flattened scenes: build time, tree size,
+"""The tree built on the device (option "tree_build" 1: top-down SAH, 3: clustering) against the host's (0) on flattened scenes: build time, tree size,
 rays per second, node visits per ray, the image checksum, and an exhaustive-loop ray query on the device-built tree.
 usage: python tools/device_build_demo.py [scene ...]      (SPP, RAYS in the environment)"""
 import os
@@ -24,7 +24,7 @@ def main():
         rng = np.random.default_rng(7)
         lo, hi = scene.vertices.min(0), scene.vertices.max(0)
         crcs = {}
-        for build in (0, 1):
+        for build in (int(x) for x in os.environ.get("BUILDS", "0 1 3").split()):
             with pa.PathTracer(0) as tr:
                 tr.set_option("instancing", 0); tr.set_option("tree_build", build)
                 t0 = time.time()
@@ -42,13 +42,13 @@ def main():
                 img = tr.read_result(); ids = tr.read_hit_ids()
                 crcs[build] = (zlib.crc32(img.tobytes()), zlib.crc32(ids.tobytes()))
                 # a second build of the same scene: what a scene change costs once the process is warm
-                tr.set_option("tree_build", 1 - build); tr.set_option("tree_build", build)
+                tr.set_option("tree_build", 1 if build == 0 else 0); tr.set_option("tree_build", build)
                 tr.render(p); tr.sync()
                 again = tr.stats()["bvh_build_ms"]
                 line = (f"  tree_build {build}: build {st0['bvh_build_ms']:8.1f} ms, again {again:8.1f} ms (first frame {first:5.2f} s)  nodes {best['bvh_nodes']:8d} depth {best['bvh_depth']:3d}  "
                         f"{best['rays'] / best['kernel_ms'] / 1e3:8.1f} Mrays/s  kernel {best['kernel_ms']:7.2f} ms  nodes/ray {best['nodes_visited'] / best['rays']:6.2f}  "
                         f"prims/ray {best['prims_tested'] / best['rays']:5.2f}  crc {crcs[build][0]} ids {crcs[build][1]}")
-                if build == 1 and n_rays:
+                if build != 0 and n_rays:
                     # rays between random points of the scene's box: the tree against the exhaustive loop, ids and distances bit for bit
                     o = (lo + (hi - lo) * rng.random((n_rays, 3))).astype(np.float32)
                     d = rng.normal(size=(n_rays, 3)).astype(np.float32)
@@ -60,7 +60,7 @@ def main():
                     same = (i1[:m] == i2).all() and (t1[:m].view(np.uint32) == t2.view(np.uint32)).all()
                     line += f"  {m} rays against the exhaustive loop: {'identical' if same else 'DIFFERENT'} ({(i2 > 0).mean():.2f} hit)"
                 print(line, flush=True)
-        print(f"  images {'identical' if crcs[0] == crcs[1] else 'DIFFERENT'}", flush=True)
+        print(f"  images {'identical' if len(set(crcs.values())) == 1 else 'DIFFERENT'}", flush=True)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,8 @@ def run(budget=60.0, seed=1):
 
     def random_scene():
         ns = int(rng.integers(0, 9)); nv = int(rng.integers(0, 40)); nt = int(rng.integers(0, 70)) if nv else 0
+        if nv and rng.random() < 0.15:         # now and then more than one wave of the device builder's last stage takes (pt_build_sah.hpp, kSahSmall)
+            nv = int(rng.integers(40, 200)); nt = int(rng.integers(130, 500))
         sph = np.zeros((ns, 14), np.float32)
         sph[:, 0:3] = rng.uniform(-4, 4, (ns, 3)); sph[:, 1] = np.abs(sph[:, 1])
         sph[:, 3] = rng.choice([0.0, -0.7, 0.3, 1.0, 2.5, 40.0], ns)
@@ -97,6 +99,7 @@ def run(budget=60.0, seed=1):
         t.set_option("bvh_width", width)
         t.set_option("split_percent", int(rng.choice([0, 30, 30, 400])))
         t.set_option("instancing", int(rng.choice([0, 1, 1, 2, 2])))
+        t.set_option("tree_build", int(rng.choice([0, 0, 1, 1, 3])))
         t.set_spheres(sph); t.set_meshes(objs, v, idx); t.set_sky(sky); t.resize(W, H)
         t.set_mesh_materials(mats)
         orc = po.Oracle(sph, objs, v, idx, sky=sky, accel=False, materials=mats)
