@@ -49,6 +49,7 @@ class PtStats(C.Structure):
 assert C.sizeof(PtSphere) == 56 and C.sizeof(PtMeshObject) == 72 and C.sizeof(PtMaterial) == 48
 
 PT_LOBE_PHONG, PT_LOBE_GGX = 0, 1
+PT_OK, PT_ERR_INVALID, PT_ERR_HIP, PT_ERR_NOMEM, PT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4      # include/ptrace.h:39-43
 
 PT_ACCUM_NONE, PT_ACCUM_MEAN, PT_ACCUM_SUM, PT_ACCUM_ADDMAT = 0, 1, 2, 3
 PT_TARGET_RESULT, PT_TARGET_CONVERGED, PT_TARGET_HIT_IDS, PT_TARGET_DENOISED, PT_TARGET_DISPLAY = 0, 1, 2, 3, 4
