@@ -486,6 +486,9 @@ def main():
             # (same primary hits and random numbers, image within a relative RMSE of 5e-3: tests/test_gpu_fast_intrinsics.py)
             out["fast_intrinsics"] = secondary_scene_rate(pa, torch, sky, name=args.scene, fast=True)
             out["value_fast_intrinsics"] = out["fast_intrinsics"]["value"]
+            # the same workload on the tree the device builds (option tree_build 1; default only from two million primitives):
+            # build_ms against bvh.build_ms above, and what its tree costs in rays per second
+            out["device_tree"] = secondary_scene_rate(pa, torch, sky, name=args.scene, device_tree=True)
             # 41 % of the headline's rays repeat a pixel's camera ray (the shader applies no jitter); this is the rate of
             # the rays that differ, i.e. of incoherent traversal
             out["value_distinct_rays"] = out["reuse_primary_hit"]["value"]
@@ -722,12 +725,14 @@ def stereo_frame_time(pa, torch, frames=30):
                       "blocks_per_cu 2 each (the two dispatches overlap)"}
 
 
-def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False, fast=False):
+def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False, fast=False, device_tree=False):
     """Mrays/s on another scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU): the ~70 k-triangle
     mesh, or (ggx) the bench scene with every mesh object given a GGX metal surface instead of the shader's
     hard-coded Phong one (PtMaterial, an extension)."""
     scene = pa.Scene(name)
     t = pa.PathTracer(torch.cuda.current_device())
+    if device_tree:   # option tree_build 1: the tree made on the device (top-down SAH) instead of by the host builder
+        t.set_option("tree_build", 1)
     t.load_scene(scene, sky); t.resize(1920, 1080)
     if fast:
         t.set_option("fast_intrinsics", 1)
@@ -735,7 +740,7 @@ def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, re
         t.set_option("reuse_primary_hit", 1)
     if ggx:
         t.set_mesh_materials(pa.materials([((0.0, 0.0, 0.0), 0.8, (0.95, 0.64, 0.54), pa.PT_LOBE_GGX)] * len(scene.objects)))
-    t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(0), spp=16, max_bounces=8)); t.stats()
+    t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(0), spp=16, max_bounces=8)); build_ms = t.stats()["bvh_build_ms"]
     t0 = time.perf_counter()
     for k in range(frames):
         t.render(pa.make_params(scene, 1920, 1080, seed=pa.frame_seed(1 + k), spp=16, max_bounces=8))
@@ -744,10 +749,12 @@ def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, re
     st = t.stats()
     t.close()
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
+            "build_ms": build_ms, "nodes_per_ray": st["nodes_visited"] / max(1, st["rays"]), "bvh_nodes": st["bvh_nodes"],
             "config": f"{name} ({scene.n_triangles} triangles + spheres + plane{', GGX copper on every mesh' if ggx else ''}), "
                       "1920x1080, 8 bounces, 16 spp, 1 GPU, one dispatch at a time"
                       + (", option reuse_primary_hit: value counts only the rays actually traced (same image)" if reuse else "")
-                      + (", option fast_intrinsics: approximate hardware transcendentals in Shade(), not bit-exact" if fast else "")}
+                      + (", option fast_intrinsics: approximate hardware transcendentals in Shade(), not bit-exact" if fast else "")
+                      + (", option tree_build 1: the tree built on the device (same image)" if device_tree else "")}
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):

@@ -164,8 +164,28 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
 
 /* Implementation switches; no counterpart in the reference.
  *   "backend"    0 (default): one persistent kernel whose waves vote between node, leaf and shade phases;
- *                1: wavefront stages - generate / persistent trace / shade+compact+regenerate (renderMode 1 only).
- *   "bvh_width"  4 (default): four-child nodes with 8-bit boxes; 2: two-child nodes with float boxes.
+ *                1: wavefront stages - generate / persistent trace / shade+compact+regenerate (renderMode 1 only);
+ *                2: the persistent kernel with a pool of rays per wave (more lanes per instruction, not faster).
+ *   "bvh_width"  4 (default): four-child nodes with 8-bit boxes; 2: two-child nodes with float boxes; 8: eight-child
+ *                nodes with their children in octant order, walked by (first child, hit mask) groups - a third fewer
+ *                node visits per ray, each dearer: 0.88x - 1.0x the rays per second of the four-child tree.
+ *   "block_order"  1 (default): a dispatch hands its 8x8-pixel blocks out most expensive first, by the cost the last
+ *                dispatch over the same rectangle measured; 0: row by row.
+ *   "fast_intrinsics"  0 (default): Shade() on the correctly rounded functions of include/ptrace_fmath.h, bit for bit the
+ *                oracle's image.  1: reciprocal, square root, exp2, log2, sine and cosine of Shade() on the hardware's
+ *                approximate instructions, short polynomials for acos and atan2 - renderMode 1 only.  The random number
+ *                stream, and with it every path's length and the primary hit ids, stay as they are; the image differs
+ *                from the exact one by a relative RMSE below 5e-3 (measured 7e-4 to 1.6e-3); +3 % to +11 % rays per second.
+ *                The only option that changes the image.
+ *   "tree_build"  Who builds the tree over whatever is not a copy of a shared mesh ("instancing").  0: the host's
+ *                binned-SAH builder (sixteen threads: 75 ms for 262 k triangles, 4.3 s for ten million).  1: the device -
+ *                Morton sort, top-down binned SAH (levels over the whole array while a node has more than 128
+ *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 7 ms and 90 ms for the
+ *                same scenes, node visits per ray within 5 % of the host tree's (rays per second 0.97x - 1.03x).
+ *                2 (default): the device from two million primitives on, the host below.  3: the device, with the
+ *                two-child tree made by locally-ordered clustering from the leaves up - a quarter of the build time
+ *                again (22 ms for ten million), a fifth more node visits per ray.  Four-child tree only; a tree too
+ *                deep for a lane's traversal stack is handed to the host builder.
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most
  *                n blocks per compute unit, which leaves room for another context's dispatch to run alongside
  *                (two eyes of a stereo pair on one GPU: 2 each).
@@ -196,7 +216,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                triangle), at most this many additional references per hundred triangles of the scene; 0: none.  A
  *                scene of evenly small triangles is left as it is; long beams and wall-sized triangles stop inflating
  *                every node above them.  A refit keeps the cuts of objects that did not move.
- * All combinations produce the same image bit for bit. */
+ * All combinations but "fast_intrinsics" 1 produce the same image bit for bit. */
 int pt_set_option(pt_context *ctx, const char *name, int value);
 
 /* _Spheres: new ComputeBuffer(count,56).SetData + SetBuffer (RayTracingMaster.cs:366-367,536).

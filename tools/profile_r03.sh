@@ -20,6 +20,8 @@ echo "phase + fast done"
 (PTRACE_BLOCK_ORDER=1 tools/pmc_write.sh order1; tools/pmc_write_size.sh base; LIB=libptrace_w4.so tools/pmc_write_size.sh w4; LIB=libptrace_w4.so WIDTHS=4 tools/ab_width.sh hall260k) > $O/write_traffic.txt 2>&1
 tools/trace_modes.sh > $O/trace_modes.log 2>&1; cp gpurun_out/prof_modes/summary.txt $O/modes_summary.txt
 PTRACE_BUILD_TIMING=1 timeout -k 10 500 python -u tools/inst_demo.py > $O/instancing.txt 2>&1
+PTRACE_BUILD_TIMING=1 RAYS=20000 timeout -k 10 500 python -u tools/device_build_demo.py > $O/device_build.txt 2>&1
+PTRACE_BUILD_TIMING=1 timeout -k 10 200 python -u tools/tree_cost_demo.py blob70k hall260k > $O/tree_cost.txt 2>&1
 tools/trace_default.sh > $O/trace_default.log 2>&1; cp gpurun_out/prof_pipelined/summary.txt $O/pipelined_trace.txt
 echo "traffic, modes, instancing, pipelined done"
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err
