@@ -299,6 +299,7 @@ __device__ __forceinline__ int32_t node_step2(const SceneDev &sc, int32_t node, 
 
 __device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
 template <class ST>
 __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, const RaySlabs &r, float tbest,
                                               const ST &st, int &sp, uint32_t *empty = nullptr)
@@ -349,9 +350,18 @@ __device__ __forceinline__ int32_t node_step4(const SceneDev &sc, int32_t node, 
     uint32_t key[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
+#ifdef PT_PACKED_SLABS
+        // measurement build: the near and the far plane of an axis in one packed instruction (v_pk_fma_f32: two IEEE fmas, the
+        // same bits); 12 vector instructions fewer per visit and 2-3 % slower on the 262 k-triangle scene
+        const float2v px = __builtin_elementwise_fma(float2v{ubyte_f(nx4, c), ubyte_f(fx4, c)}, float2v{sx, sx}, float2v{bx, bx});
+        const float2v py = __builtin_elementwise_fma(float2v{ubyte_f(ny4, c), ubyte_f(fy4, c)}, float2v{sy, sy}, float2v{by, by});
+        const float2v pz = __builtin_elementwise_fma(float2v{ubyte_f(nz4, c), ubyte_f(fz4, c)}, float2v{sz, sz}, float2v{bz, bz});
+        const float nx = px.x, fx = px.y, ny = py.x, fy = py.y, nz = pz.x, fz = pz.y;
+#else
         float nx = __builtin_fmaf(ubyte_f(nx4, c), sx, bx), fx = __builtin_fmaf(ubyte_f(fx4, c), sx, bx);
         float ny = __builtin_fmaf(ubyte_f(ny4, c), sy, by), fy = __builtin_fmaf(ubyte_f(fy4, c), sy, by);
         float nz = __builtin_fmaf(ubyte_f(nz4, c), sz, bz), fz = __builtin_fmaf(ubyte_f(fz4, c), sz, bz);
+#endif
         float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
         float tf = fminf(fminf(fx, fy), fz);
         bool hit = tn <= tf * 1.000002f && tn <= tbest;   // an unused slot holds an inside-out box: never entered
