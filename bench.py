@@ -486,9 +486,9 @@ def main():
             # (same primary hits and random numbers, image within a relative RMSE of 5e-3: tests/test_gpu_fast_intrinsics.py)
             out["fast_intrinsics"] = secondary_scene_rate(pa, torch, sky, name=args.scene, fast=True)
             out["value_fast_intrinsics"] = out["fast_intrinsics"]["value"]
-            # the same workload on the tree the device builds (option tree_build 1; default only from two million primitives):
-            # build_ms against bvh.build_ms above, and what its tree costs in rays per second
-            out["device_tree"] = secondary_scene_rate(pa, torch, sky, name=args.scene, device_tree=True)
+            # the same workload on the tree the host builder makes (option tree_build 0; the default builds on the device):
+            # build_ms against bvh.build_ms above, and the rays per second of its tree
+            out["host_tree"] = secondary_scene_rate(pa, torch, sky, name=args.scene, host_tree=True)
             # 41 % of the headline's rays repeat a pixel's camera ray (the shader applies no jitter); this is the rate of
             # the rays that differ, i.e. of incoherent traversal
             out["value_distinct_rays"] = out["reuse_primary_hit"]["value"]
@@ -725,14 +725,14 @@ def stereo_frame_time(pa, torch, frames=30):
                       "blocks_per_cu 2 each (the two dispatches overlap)"}
 
 
-def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False, fast=False, device_tree=False):
+def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, reuse=False, fast=False, host_tree=False):
     """Mrays/s on another scene at the headline settings (1920x1080, 8 bounces, 16 spp, one GPU): the ~70 k-triangle
     mesh, or (ggx) the bench scene with every mesh object given a GGX metal surface instead of the shader's
     hard-coded Phong one (PtMaterial, an extension)."""
     scene = pa.Scene(name)
     t = pa.PathTracer(torch.cuda.current_device())
-    if device_tree:   # option tree_build 1: the tree made on the device (top-down SAH) instead of by the host builder
-        t.set_option("tree_build", 1)
+    if host_tree:   # option tree_build 0: the tree made by the host builder instead of on the device (the default from 16 k primitives on)
+        t.set_option("tree_build", 0)
     t.load_scene(scene, sky); t.resize(1920, 1080)
     if fast:
         t.set_option("fast_intrinsics", 1)
@@ -754,7 +754,7 @@ def secondary_scene_rate(pa, torch, sky, frames=5, name="blob70k", ggx=False, re
                       "1920x1080, 8 bounces, 16 spp, 1 GPU, one dispatch at a time"
                       + (", option reuse_primary_hit: value counts only the rays actually traced (same image)" if reuse else "")
                       + (", option fast_intrinsics: approximate hardware transcendentals in Shade(), not bit-exact" if fast else "")
-                      + (", option tree_build 1: the tree built on the device (same image)" if device_tree else "")}
+                      + (", option tree_build 0: the tree built by the host's SAH builder (same image)" if host_tree else "")}
 
 
 def reproj_frame_time(pa, torch, scene, sky, frames=30):

@@ -82,6 +82,8 @@ struct Builder {
             }
         }
         node.box = box; node.first = first; node.count = 0;
+        static const bool bin_by_box = std::getenv("PTRACE_HOST_BIN_BOX") != nullptr;      // measurement knob: bins over the box, as the device builder's
+        if (bin_by_box) cbox = box;
         int d = max_depth.load();
         while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
 

@@ -77,44 +77,63 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// How the reductions over the whole primitive array are laid out: every wave takes kWaveChunk consecutive places, 64 at a
+// time, and sends its atomics once per chunk (or whenever the thing it reduces for changes) - one atomic per wave and per 64
+// primitives, all on the same few words, is ten milliseconds of serialised traffic for ten million primitives.
+constexpr int kWaveChunk = 64 * 32;
+__host__ __device__ inline size_t wave_chunk_blocks(size_t n) { return (n + (size_t)kWaveChunk * (kBuildBlock / 64) - 1) / ((size_t)kWaveChunk * (kBuildBlock / 64)); }
+
 // scene_box: 6 ordered words (lo.xyz from +inf, hi.xyz from -inf) over the world-space vertices; object_box: the same per
 // object over its object-space vertices.  Coordinates that are NaN or beyond kHugeCoord take no part (bvh.hpp).
 __global__ __launch_bounds__(kBuildBlock) void build_bounds_kernel(const BuildScene s, uint32_t *scene_box, uint32_t *object_box)
 {
-    int gid = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (gid >= s.n_tris) gid = s.n_tris - 1;            // a duplicate changes no minimum; every lane stays in the reductions below
-    const int o = object_of(s, gid);
-    const int4 ob = s.objects[o];
-    const int32_t *ix = s.indices + (size_t)ob.y + 3 * (size_t)(gid - ob.x);
-    float mm[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) mm[k] = s.matrices[16 * (size_t)o + k];
-    float olo[3] = {PT_INF, PT_INF, PT_INF}, ohi[3] = {-PT_INF, -PT_INF, -PT_INF};
-    float wlo[3] = {PT_INF, PT_INF, PT_INF}, whi[3] = {-PT_INF, -PT_INF, -PT_INF};
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float *p = s.vertices + 3 * (size_t)ix[c];
-        const float v[3] = {p[0], p[1], p[2]};
-        const f3 w = pt_mul_point(mm, pt_make3(v[0], v[1], v[2]));      // RayTracingShader.compute:238-240
-        const float wv[3] = {w.x, w.y, w.z};
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = ((size_t)blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6)) * kWaveChunk;
+    if (chunk >= (size_t)s.n_tris) return;
+    float wlo[3] = {PT_INF, PT_INF, PT_INF}, whi[3] = {-PT_INF, -PT_INF, -PT_INF};      // this lane's share of the scene box
+    float olo[3] = {PT_INF, PT_INF, PT_INF}, ohi[3] = {-PT_INF, -PT_INF, -PT_INF};      // and of the object the wave is in
+    int held = -1;                                                                       // that object (the same in every lane)
+    const auto flush_object = [&]() {
+        if (held < 0) return;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            if (fabsf(v[k]) < kHugeCoord) { olo[k] = fminf(olo[k], v[k]); ohi[k] = fmaxf(ohi[k], v[k]); }
-            if (fabsf(wv[k]) < kHugeCoord) { wlo[k] = fminf(wlo[k], wv[k]); whi[k] = fmaxf(whi[k], wv[k]); }
+            const float a = wave_min(olo[k]), b = wave_max(ohi[k]);
+            if (lane == 0 && a <= b) { atomicMin(object_box + 6 * (size_t)held + k, ordered_bits(a)); atomicMax(object_box + 6 * (size_t)held + 3 + k, ordered_bits(b)); }
+            olo[k] = PT_INF; ohi[k] = -PT_INF;
+        }
+    };
+    for (int step = 0; step < kWaveChunk / 64; step++) {
+        const size_t first = chunk + (size_t)step * 64;
+        if (first >= (size_t)s.n_tris) break;
+        const int gid = (int)min(first + (size_t)lane, (size_t)s.n_tris - 1);           // a duplicate changes no minimum
+        const int o = object_of(s, gid);
+        const int4 ob = s.objects[o];
+        const int32_t *ix = s.indices + (size_t)ob.y + 3 * (size_t)(gid - ob.x);
+        float mm[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) mm[k] = s.matrices[16 * (size_t)o + k];
+        const bool one_object = __all(o == __builtin_amdgcn_readfirstlane(o));
+        if (!one_object || o != held) { flush_object(); held = one_object ? o : -1; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float *p = s.vertices + 3 * (size_t)ix[c];
+            const float v[3] = {p[0], p[1], p[2]};
+            const f3 w = pt_mul_point(mm, pt_make3(v[0], v[1], v[2]));      // RayTracingShader.compute:238-240
+            const float wv[3] = {w.x, w.y, w.z};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (fabsf(wv[k]) < kHugeCoord) { wlo[k] = fminf(wlo[k], wv[k]); whi[k] = fmaxf(whi[k], wv[k]); }
+                if (!(fabsf(v[k]) < kHugeCoord)) continue;
+                if (one_object) { olo[k] = fminf(olo[k], v[k]); ohi[k] = fmaxf(ohi[k], v[k]); }
+                else { atomicMin(object_box + 6 * (size_t)o + k, ordered_bits(v[k])); atomicMax(object_box + 6 * (size_t)o + 3 + k, ordered_bits(v[k])); }
+            }
         }
     }
-    const bool one_object = __all(o == __builtin_amdgcn_readfirstlane(o));
-    const bool first = (threadIdx.x & 63) == 0;
+    flush_object();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float l = wave_min(wlo[k]), h = wave_max(whi[k]);
-        if (first && l <= h) { atomicMin(scene_box + k, ordered_bits(l)); atomicMax(scene_box + 3 + k, ordered_bits(h)); }
-        if (one_object) {
-            const float a = wave_min(olo[k]), b = wave_max(ohi[k]);
-            if (first && a <= b) { atomicMin(object_box + 6 * (size_t)o + k, ordered_bits(a)); atomicMax(object_box + 6 * (size_t)o + 3 + k, ordered_bits(b)); }
-        } else if (olo[k] <= ohi[k]) {
-            atomicMin(object_box + 6 * (size_t)o + k, ordered_bits(olo[k])); atomicMax(object_box + 6 * (size_t)o + 3 + k, ordered_bits(ohi[k]));
-        }
+        if (lane == 0 && l <= h) { atomicMin(scene_box + k, ordered_bits(l)); atomicMax(scene_box + 3 + k, ordered_bits(h)); }
     }
 }
 
@@ -140,6 +159,22 @@ __global__ __launch_bounds__(kBuildBlock) void build_prims_kernel(const BuildSce
     prims[(size_t)p * 3 + 0] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(1 + p));
     prims[(size_t)p * 3 + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     prims[(size_t)p * 3 + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// How many triangles the host builder would consider cutting into several references (bvh.cpp, split_references: a box
+// that spans a sixteenth of the scene's largest extent).  The device builders do not cut; when the caller leaves the choice
+// of builder open, a scene with such triangles goes to the host's.
+__global__ __launch_bounds__(kBuildBlock) void count_large_kernel(const float *box, int first, int n, float threshold, uint32_t *count)
+{
+    const int p = first + blockIdx.x * kBuildBlock + threadIdx.x;
+    bool large = false;
+    if (p < n) {
+        const float *b = box + (size_t)p * 6;
+        const float e = fmaxf(fmaxf(b[3] - b[0], b[4] - b[1]), b[5] - b[2]);
+        large = e >= threshold && e < kHugeCoord;       // (a NaN or huge coordinate is not cut either)
+    }
+    const unsigned long long m = __ballot(large);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
 }
 
 __device__ __forceinline__ uint64_t spread21(uint32_t v)      // bit i of v to bit 3 i

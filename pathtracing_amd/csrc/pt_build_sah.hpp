@@ -8,10 +8,11 @@
 //
 //   upper levels, one pass per level over all primitives (they lie in Morton order, and a stable partition keeps every
 //   node's primitives one contiguous, still Morton-ordered range):
-//     sah_bin_kernel        every primitive of a node with more than kSahSmall adds its box to one of 16 bins per axis of
-//                           its node (by its centre's place in the node's box); a block first collects, in LDS, what goes
+//     sah_centres_kernel    the bounds of the box centres of every node's primitives: the range its bins are laid over
+//     sah_bin_kernel        every primitive of a node with more than kSahSmall adds its box to one of 32 bins per axis of
+//                           its node (by its centre's place among the node's centres); a block first collects, in LDS, what goes
 //                           to the node of its first primitive - near the root that is everything
-//     sah_split_kernel      per node: the cheapest of the 45 bin boundaries, area(left) n_left + area(right) n_right; the
+//     sah_split_kernel      per node: the cheapest of the 93 bin boundaries, area(left) n_left + area(right) n_right; the
 //                           two children get numbers, boxes (exact: unions of bins) and ranges
 //     sah_next_kernel       children with more than kSahSmall primitives form the next level, the others go on a list
 //     sah_side_kernel, scan, sah_partition_kernel   left primitives to the front of the node's range, order kept
@@ -24,9 +25,10 @@
 
 namespace ptrace {
 
-constexpr int kSahBins = 16;           // 32, the host builder's count, gave 1-2 % MORE node visits per ray here (15.79 against 15.62 on the 262 k-triangle hall)
+constexpr int kSahBins = 32;           // the host builder's count (bvh.cpp, kBins)
 constexpr int kSahBinWords = 3 * kSahBins * 7;       // per node: [axis][bin] (lo.xyz as ordered words, hi.xyz, count)
 constexpr int kSahSmall = 128;
+constexpr int kSahExhaustive = 8;       // ranges this small are split by trying every two-part split
 
 struct SahRange {
     float lo[3]; int32_t begin;        // box of the range's primitives; first place in the primitive array
@@ -46,17 +48,24 @@ __device__ __forceinline__ float sah_scale(float lo, float hi)
     return ext > 0.0f && ext < PT_INF ? (float)kSahBins / ext : 0.0f;
 }
 
-// The box of all primitives: 6 ordered words, lo from 0xffffffff, hi from 0.
+// The box of all primitives: 6 ordered words, lo from 0xffffffff, hi from 0.  (Chunks per wave: pt_build.hpp, kWaveChunk.)
 __global__ __launch_bounds__(kBuildBlock) void sah_bounds_kernel(const float4 *p_lo, const float4 *p_hi, int n, uint32_t *bounds)
 {
-    int i = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (i >= n) i = n - 1;
-    const float4 a = p_lo[i], b = p_hi[i];
-    const float l[3] = {a.x, a.y, a.z}, h[3] = {b.x, b.y, b.z};
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = ((size_t)blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6)) * kWaveChunk;
+    if (chunk >= (size_t)n) return;
+    float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
+    for (int step = 0; step < kWaveChunk / 64; step++) {
+        const size_t i = chunk + (size_t)step * 64 + lane;
+        if (i >= (size_t)n) break;
+        const float4 a = p_lo[i], b = p_hi[i];
+        l[0] = fminf(l[0], a.x); l[1] = fminf(l[1], a.y); l[2] = fminf(l[2], a.z);
+        h[0] = fmaxf(h[0], b.x); h[1] = fmaxf(h[1], b.y); h[2] = fmaxf(h[2], b.z);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float wl = wave_min(l[k]), wh = wave_max(h[k]);
-        if ((threadIdx.x & 63) == 0) { atomicMin(bounds + k, ordered_bits(wl)); atomicMax(bounds + 3 + k, ordered_bits(wh)); }
+        if (lane == 0) { atomicMin(bounds + k, ordered_bits(wl)); atomicMax(bounds + 3 + k, ordered_bits(wh)); }
     }
 }
 
@@ -68,45 +77,107 @@ __global__ __launch_bounds__(kBuildBlock) void sah_fill_kernel(uint32_t *bins, s
     bins[w] = k < 3 ? 0xffffffffu : 0u;
 }
 
-// seg[i]: this level's node of the primitive at place i (an index into `act`), or -1 once it lies in a listed node.
-__global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, uint32_t *bins)
+// cb[a]: the bounds of the box CENTRES of node a's primitives, 6 ordered words (lo from 0xffffffff, hi from 0) - the range the
+// bins are laid over.  (Over the node's box instead, the host builder's tree of the 262 k-triangle hall costs 15.80 node visits
+// per ray instead of 14.97: half a primitive of slack at either end is a bin or two of sixteen once nodes get small.)  A node's
+// primitives are contiguous, so nearly every wave holds one node and sends six atomics.
+__global__ __launch_bounds__(kBuildBlock) void sah_fill_centres_kernel(uint32_t *cb, int words)
 {
-    __shared__ uint32_t local[kSahBinWords];
-    const int first = blockIdx.x * kBuildBlock;
-    const int home = seg[first];
-    for (int w = threadIdx.x; w < kSahBinWords; w += kBuildBlock) local[w] = (w % 7) < 3 ? 0xffffffffu : 0u;
-    __syncthreads();
-    const int i = first + threadIdx.x;
-    if (i < n) {
+    const int w = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (w < words) cb[w] = (w % 6) < 3 ? 0xffffffffu : 0u;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void sah_centres_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, uint32_t *cb)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = ((size_t)blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6)) * kWaveChunk;
+    if (chunk >= (size_t)n) return;
+    float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};      // this lane's share of node `held`
+    int held = -1;                                                                   // the same in every lane
+    const auto flush = [&]() {
+        if (held < 0) return;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float a = wave_min(l[k]), b = wave_max(h[k]);
+            if (lane == 0 && a <= b) { atomicMin(cb + (size_t)held * 6 + k, ordered_bits(a)); atomicMax(cb + (size_t)held * 6 + 3 + k, ordered_bits(b)); }
+            l[k] = PT_INF; h[k] = -PT_INF;
+        }
+    };
+    for (int step = 0; step < kWaveChunk / 64; step++) {
+        const size_t first = chunk + (size_t)step * 64;
+        if (first >= (size_t)n) break;
+        const size_t i = min(first + (size_t)lane, (size_t)n - 1);                   // a duplicate changes no minimum
         const int a = seg[i];
-        if (a >= 0) {
-            const SahRange r = act[a];
-            const float4 pl = p_lo[i], ph = p_hi[i];
-            const float l[3] = {pl.x, pl.y, pl.z}, h[3] = {ph.x, ph.y, ph.z};
-            uint32_t ol[3], oh[3];
+        const bool one_node = __all(a == __builtin_amdgcn_readfirstlane(a));
+        if (!one_node || a != held) { flush(); held = one_node ? a : -1; }
+        if (a < 0) continue;
+        const float4 pl = p_lo[i], ph = p_hi[i];
+        const float c[3] = {0.5f * pl.x + 0.5f * ph.x, 0.5f * pl.y + 0.5f * ph.y, 0.5f * pl.z + 0.5f * ph.z};
 #pragma unroll
-            for (int k = 0; k < 3; k++) { ol[k] = ordered_bits(l[k]); oh[k] = ordered_bits(h[k]); }
-            uint32_t *dst = a == home ? local : bins + (size_t)a * kSahBinWords;
-#pragma unroll
-            for (int ax = 0; ax < 3; ax++) {
-                uint32_t *w = dst + (ax * kSahBins + sah_bin(l[ax], h[ax], r.lo[ax], sah_scale(r.lo[ax], r.hi[ax]))) * 7;
-#pragma unroll
-                for (int k = 0; k < 3; k++) { atomicMin(w + k, ol[k]); atomicMax(w + 3 + k, oh[k]); }
-                atomicAdd(w + 6, 1u);
-            }
+        for (int k = 0; k < 3; k++) {
+            if (one_node) { l[k] = fminf(l[k], c[k]); h[k] = fmaxf(h[k], c[k]); }
+            else { atomicMin(cb + (size_t)a * 6 + k, ordered_bits(c[k])); atomicMax(cb + (size_t)a * 6 + 3 + k, ordered_bits(c[k])); }
         }
     }
-    __syncthreads();
-    if (home < 0) return;
-    uint32_t *dst = bins + (size_t)home * kSahBinWords;
-    for (int w = threadIdx.x; w < kSahBinWords; w += kBuildBlock) {
-        const uint32_t v = local[w], k = (uint32_t)(w % 7);
-        if (k < 3) { if (v != 0xffffffffu) atomicMin(dst + w, v); }
-        else if (v) { if (k < 6) atomicMax(dst + w, v); else atomicAdd(dst + w, v); }
-    }
+    flush();
 }
 
 __device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+// seg[i]: this level's node of the primitive at place i (an index into `act`), or -1 once it lies in a listed node.
+// Every wave takes kBinChunk consecutive places, 64 at a time, and collects in LDS bins of its own what goes to its `home`
+// node - the node all 64 places of a step belong to; when that changes, the bins are sent to the old home's global bins and
+// start again.  Nodes are contiguous and hold more than kSahSmall primitives, so nearly everything goes through LDS at every
+// level: a few dozen global atomics per node and wave instead of 21 per primitive.  Lanes of a step that straddles two nodes
+// send what is not home's to the global bins directly.  (Only the wave itself touches its bins: no block barrier.)
+constexpr int kBinChunk = 64 * 8;
+__global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const uint32_t *cb, uint32_t *bins)
+{
+    __shared__ uint32_t local_bins[kBuildBlock / 64][kSahBinWords];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *local = local_bins[wave];
+    const size_t first = ((size_t)blockIdx.x * (kBuildBlock / 64) + wave) * kBinChunk;
+    if (first >= (size_t)n) return;
+    for (int w = lane; w < kSahBinWords; w += 64) local[w] = (w % 7) < 3 ? 0xffffffffu : 0u;
+    int home = -1;
+    const auto flush = [&]() {          // the wave's bins into home's, and empty again
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (home >= 0) {
+            uint32_t *dst = bins + (size_t)home * kSahBinWords;
+            for (int w = lane; w < kSahBinWords; w += 64) {
+                const uint32_t v = local[w], k = (uint32_t)(w % 7);
+                if (k < 3) { if (v != 0xffffffffu) { atomicMin(dst + w, v); local[w] = 0xffffffffu; } }
+                else if (v) { if (k < 6) atomicMax(dst + w, v); else atomicAdd(dst + w, v); local[w] = 0u; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    };
+    for (int step = 0; step < kBinChunk / 64; step++) {
+        const size_t at = first + (size_t)step * 64;
+        if (at >= (size_t)n) break;
+        const size_t i = at + lane;
+        const int a = i < (size_t)n ? seg[i] : -1;
+        const int lead = __builtin_amdgcn_readfirstlane(a);
+        if (lead >= 0 && lead != home && __all(a == lead)) { flush(); home = lead; }
+        if (a < 0) continue;
+        const uint32_t *r = cb + (size_t)a * 6;
+        const float4 pl = p_lo[i], ph = p_hi[i];
+        const float l[3] = {pl.x, pl.y, pl.z}, h[3] = {ph.x, ph.y, ph.z};
+        uint32_t ol[3], oh[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ol[k] = ordered_bits(l[k]); oh[k] = ordered_bits(h[k]); }
+        uint32_t *dst = a == home ? local : bins + (size_t)a * kSahBinWords;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            const float rl = ordered_to_float(r[ax]), rh = ordered_to_float(r[3 + ax]);
+            uint32_t *w = dst + (ax * kSahBins + sah_bin(l[ax], h[ax], rl, sah_scale(rl, rh))) * 7;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { atomicMin(w + k, ol[k]); atomicMax(w + 3 + k, oh[k]); }
+            atomicAdd(w + 6, 1u);
+        }
+    }
+    flush();
+}
 
 struct SahBox { float l[3], h[3]; uint32_t n; };
 __device__ __forceinline__ void sah_box_reset(SahBox &b) { for (int k = 0; k < 3; k++) { b.l[k] = PT_INF; b.h[k] = -PT_INF; } b.n = 0; }
@@ -181,7 +252,8 @@ __global__ __launch_bounds__(kBuildBlock) void sah_next_kernel(const SahRange *c
     else { small[small_base + (int)(o >> 32)] = cand[c]; slot[c] = -1; }
 }
 
-__global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, const int4 *split, uint32_t *left)
+__global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, const uint32_t *cb, const int4 *split,
+                                                               uint32_t *left)
 {
     const int i = blockIdx.x * kBuildBlock + threadIdx.x;
     if (i >= n) return;
@@ -191,7 +263,7 @@ __global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_l
         const int4 sp = split[a];
         if (sp.x < 0) l = i - act[a].begin < sp.z;
         else {
-            const float rl = act[a].lo[sp.x], rh = act[a].hi[sp.x];
+            const float rl = ordered_to_float(cb[(size_t)a * 6 + sp.x]), rh = ordered_to_float(cb[(size_t)a * 6 + 3 + sp.x]);
             const float4 pl = p_lo[i], ph = p_hi[i];
             const float lo = sp.x == 0 ? pl.x : sp.x == 1 ? pl.y : pl.z, hi = sp.x == 0 ? ph.x : sp.x == 1 ? ph.y : ph.z;
             l = sah_bin(lo, hi, rl, sah_scale(rl, rh)) <= sp.y;
@@ -260,21 +332,58 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
         sp--;
         const int b = stack_begin[sp], e = stack_end[sp], node = stack_node[sp], k = e - b;
         __syncthreads();                     // everyone has read the entry before it is overwritten
-        float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
+        float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};          // the range's box
+        float cl[3] = {PT_INF, PT_INF, PT_INF}, ch[3] = {-PT_INF, -PT_INF, -PT_INF};        // and the bounds of its box centres
         for (int i = b + lane; i < e; i += 64) {
             const int p = order[0][i];
 #pragma unroll
-            for (int ax = 0; ax < 3; ax++) { l[ax] = fminf(l[ax], blo[ax][p]); h[ax] = fmaxf(h[ax], bhi[ax][p]); }
+            for (int ax = 0; ax < 3; ax++) {
+                l[ax] = fminf(l[ax], blo[ax][p]); h[ax] = fmaxf(h[ax], bhi[ax][p]);
+                const float c = 0.5f * blo[ax][p] + 0.5f * bhi[ax][p];
+                cl[ax] = fminf(cl[ax], c); ch[ax] = fmaxf(ch[ax], c);
+            }
         }
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) { l[ax] = wave_min(l[ax]); h[ax] = wave_max(h[ax]); }
+        for (int ax = 0; ax < 3; ax++) { l[ax] = wave_min(l[ax]); h[ax] = wave_max(h[ax]); cl[ax] = wave_min(cl[ax]); ch[ax] = wave_max(ch[ax]); }
         int n_left = 1;
-        if (k > 2) {
+        if (k > 2 && k <= kSahExhaustive) {
+            // a handful of primitives: every split into two parts, shared out over the lanes - exact where sixteen bins
+            // would be guessing.  Part `sub` (a mask over the range's places, the first place always in it) against the rest.
+            const uint32_t full = (1u << k) - 1u;
+            float best = PT_INF; uint32_t best_sub = 1u;
+            for (uint32_t c = (uint32_t)lane; c + 1u < (1u << (k - 1)); c += 64u) {
+                const uint32_t sub = (c << 1) | 1u;
+                SahBox lb, rb; sah_box_reset(lb); sah_box_reset(rb);
+                for (int j = 0; j < k; j++) {
+                    const int p = order[0][b + j];
+                    SahBox &t = ((sub >> j) & 1u) ? lb : rb;
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) { t.l[ax] = fminf(t.l[ax], blo[ax][p]); t.h[ax] = fmaxf(t.h[ax], bhi[ax][p]); }
+                    t.n++;
+                }
+                const float cost = sah_box_cost(lb) + sah_box_cost(rb);
+                if (cost < best || (cost == best && sub < best_sub)) { best = cost; best_sub = sub; }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float oc = __shfl_xor(best, d, 64); const uint32_t os = __shfl_xor(best_sub, d, 64);
+                if (oc < best || (oc == best && os < best_sub)) { best = oc; best_sub = os; }
+            }
+            n_left = __popc(best_sub);
+            if (lane < k) {              // the members of best_sub to the front, order kept on both sides
+                const uint32_t below = (1u << lane) - 1u;
+                const int pos = ((best_sub >> lane) & 1u) ? __popc(best_sub & below) : n_left + __popc(~best_sub & full & below);
+                order[1][b + pos] = order[0][b + lane];
+            }
+            __syncthreads();
+            if (lane < k) order[0][b + lane] = order[1][b + lane];
+            __syncthreads();
+        } else if (k > 2) {
             for (int w = lane; w < kSahBinWords; w += 64) bins[w] = (w % 7) < 3 ? 0xffffffffu : 0u;
             __syncthreads();
             float scale[3];
 #pragma unroll
-            for (int ax = 0; ax < 3; ax++) scale[ax] = sah_scale(l[ax], h[ax]);
+            for (int ax = 0; ax < 3; ax++) scale[ax] = sah_scale(cl[ax], ch[ax]);
             for (int i = b + lane; i < e; i += 64) {
                 const int p = order[0][i];
                 uint32_t ol[3], oh[3];
@@ -282,22 +391,44 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
                 for (int ax = 0; ax < 3; ax++) { ol[ax] = ordered_bits(blo[ax][p]); oh[ax] = ordered_bits(bhi[ax][p]); }
 #pragma unroll
                 for (int ax = 0; ax < 3; ax++) {
-                    uint32_t *w = bins + (ax * kSahBins + sah_bin(blo[ax][p], bhi[ax][p], l[ax], scale[ax])) * 7;
+                    uint32_t *w = bins + (ax * kSahBins + sah_bin(blo[ax][p], bhi[ax][p], cl[ax], scale[ax])) * 7;
 #pragma unroll
                     for (int q = 0; q < 3; q++) { atomicMin(w + q, ol[q]); atomicMax(w + 3 + q, oh[q]); }
                     atomicAdd(w + 6, 1u);
                 }
             }
             __syncthreads();
-            // candidate c = axis * (kSahBins - 1) + s: the split after bin s of that axis; the lanes share them out
+            // candidate c = axis * (kSahBins - 1) + s: the split after bin s of that axis.  Two rounds of 32-lane halves, a
+            // half per axis: every lane takes a bin, prefix and suffix unions run over the half (five shuffle steps each), and
+            // the lane of bin s prices "bins 0..s against s+1..31".
+            static_assert(kSahBins == 32, "one bin per lane of a half-wave");
             float best = PT_INF; int best_cand = 3 * (kSahBins - 1); uint32_t my_left = 0;
-            for (int c = lane; c < 3 * (kSahBins - 1); c += 64) {
-                const int ax = c / (kSahBins - 1), s = c % (kSahBins - 1);
-                SahBox lb, rb; sah_box_reset(lb); sah_box_reset(rb);
-                for (int q = 0; q < kSahBins; q++) sah_box_add(q <= s ? lb : rb, bins + (ax * kSahBins + q) * 7);
-                if (!lb.n || !rb.n) continue;
-                const float cost = sah_box_cost(lb) + sah_box_cost(rb);
-                if (cost < best) { best = cost; best_cand = c; my_left = lb.n; }
+            for (int round = 0; round < 2; round++) {
+                const int ax = 2 * round + (lane >> 5), bin = lane & 31;
+                SahBox pre; sah_box_reset(pre);
+                if (ax < 3) sah_box_add(pre, bins + (ax * kSahBins + bin) * 7);
+                SahBox suf = pre;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    SahBox up, down;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        up.l[q] = __shfl_up(pre.l[q], d, 32); up.h[q] = __shfl_up(pre.h[q], d, 32);
+                        down.l[q] = __shfl_down(suf.l[q], d, 32); down.h[q] = __shfl_down(suf.h[q], d, 32);
+                    }
+                    up.n = __shfl_up(pre.n, d, 32); down.n = __shfl_down(suf.n, d, 32);
+                    if (bin >= d) { for (int q = 0; q < 3; q++) { pre.l[q] = fminf(pre.l[q], up.l[q]); pre.h[q] = fmaxf(pre.h[q], up.h[q]); } pre.n += up.n; }
+                    if (bin + d < 32) { for (int q = 0; q < 3; q++) { suf.l[q] = fminf(suf.l[q], down.l[q]); suf.h[q] = fmaxf(suf.h[q], down.h[q]); } suf.n += down.n; }
+                }
+                SahBox right;            // bins bin + 1 .. 31: the neighbour's suffix
+#pragma unroll
+                for (int q = 0; q < 3; q++) { right.l[q] = __shfl_down(suf.l[q], 1, 32); right.h[q] = __shfl_down(suf.h[q], 1, 32); }
+                right.n = __shfl_down(suf.n, 1, 32);
+                if (ax < 3 && bin < kSahBins - 1 && pre.n && right.n) {
+                    const float cost = sah_box_cost(pre) + sah_box_cost(right);
+                    const int c = ax * (kSahBins - 1) + bin;
+                    if (cost < best) { best = cost; best_cand = c; my_left = pre.n; }
+                }
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
@@ -312,7 +443,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
                     const int i = base + lane;
                     const bool valid = i < e;
                     const int p = valid ? order[0][i] : 0;
-                    const bool left = valid && sah_bin(blo[ax][p], bhi[ax][p], l[ax], scale[ax]) <= s;
+                    const bool left = valid && sah_bin(blo[ax][p], bhi[ax][p], cl[ax], scale[ax]) <= s;
                     const unsigned long long ml = __ballot(left), mr = __ballot(valid && !left);
                     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
                     if (left) order[1][b + done_left + __popcll(ml & below)] = (uint8_t)p;

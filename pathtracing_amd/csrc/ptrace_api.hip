@@ -122,8 +122,8 @@ struct pt_context {
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
     // option "tree_build": 0 the host's binned-SAH builder; 1 the device builder (pt_build.hpp; top-down SAH, pt_build_sah.hpp) for
     // whatever is not a copy of a shared mesh; 2 (default) the device builder for scenes of kDeviceBuildMinPrims primitives or
-    // more; 3 the device builder with its two-child tree made by clustering - a quarter of the build time, a fifth fewer rays
-    // per second
+    // more without triangles the host builder would cut into references; 3 the device builder with its two-child tree made by
+    // clustering - half the build time again, a fifth more node visits per ray
     int tree_build = 2;
     bool device_built = false;        // the last build ran on the device: a four-wide tree only, like `expanded`
     float4 *d_inst = nullptr;         // SceneDev::inst
@@ -506,7 +506,7 @@ int refit_expanded(pt_context *ctx, const RefitArgs &ra)
 }
 
 // ---- the tree built on the device (pt_build.hpp) ----------------------------------------------------------------
-constexpr size_t kDeviceBuildMinPrims = 2000000;     // option tree_build 2: scenes below this build on the host (its tree is a little better)
+constexpr size_t kDeviceBuildMinPrims = 16384;       // option tree_build 2: scenes below this build on the host (done before a device allocation would be)
 constexpr int kDeviceBuildFallback = -1000;          // not an error: the caller goes on with the host build
 constexpr int kDeviceBuildMaxLevels = 2048;
 constexpr int kDeviceBuildTopClusters = 8192;        // clusters at which the clustering rounds stop and the host builds the top of the tree
@@ -525,7 +525,7 @@ struct DeviceArena {
 // The scene as pt_set_spheres / pt_set_meshes left it, every mesh object flattened (RayTracingShader.compute:236-240 applied
 // once instead of per ray), as a four-wide tree made on the device.  The host touches the objects and the spheres, never a
 // triangle.  Leaves the context exactly as the host build of a flat scene does, minus the two-child tree.
-int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt)
+int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt, bool unless_large_triangles)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const int nS = (int)ctx->spheres.size();
@@ -567,7 +567,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         int32_t *items[2], *stacked[2]; int4 *kids;
         uint4 *nodes4; uint32_t *slot_prim, *slot_prim_dfs; int32_t *stack_need;
         int2 *below, *place;
-        SahRange *act[2], *cand, *small; int32_t *slot; int4 *split; uint32_t *bins;
+        SahRange *act[2], *cand, *small; int32_t *slot; int4 *split; uint32_t *bins, *centres;
         char *temp;
     } d{};
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -594,7 +594,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         a.take(d.kids, nP); a.take(d.nodes4, nP * 4); a.take(d.slot_prim, nP + 1); a.take(d.slot_prim_dfs, nP + 1); a.take(d.stack_need, 64);
         a.take(d.below, nP); a.take(d.place, nP);
         a.take(d.act[0], sah_nodes); a.take(d.act[1], sah_nodes); a.take(d.cand, 2 * sah_nodes); a.take(d.small, nP); a.take(d.slot, 2 * sah_nodes); a.take(d.split, sah_nodes);
-        a.take(d.bins, sah_nodes * kSahBinWords);
+        a.take(d.bins, sah_nodes * kSahBinWords); a.take(d.centres, sah_nodes * 6);
         a.take(d.temp, temp_bytes);
     };
     DeviceArena arena;
@@ -619,7 +619,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     BuildScene bs;
     bs.vertices = ctx->d_vertices; bs.indices = d.indices; bs.matrices = ctx->d_matrices; bs.objects = d.objects; bs.spheres = ctx->d_sphere_mat;
     bs.n_objects = (int32_t)nO; bs.n_spheres = nS; bs.n_tris = (int32_t)nt;
-    if (nt) hipLaunchKernelGGL(build_bounds_kernel, grid(nt), dim3(kBuildBlock), 0, st, bs, d.bounds + 6 * nO, d.bounds);
+    if (nt) hipLaunchKernelGGL(build_bounds_kernel, dim3((unsigned)wave_chunk_blocks(nt)), dim3(kBuildBlock), 0, st, bs, d.bounds + 6 * nO, d.bounds);
     PT_HIP(ctx, hipGetLastError());
     PT_HIP(ctx, hipMemcpyAsync(bounds.data(), d.bounds, n_bounds * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PT_HIP(ctx, hipStreamSynchronize(st));
@@ -659,6 +659,16 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     ra.slot_clip = nullptr; ra.build_matrices = nullptr; ra.nodes4 = nullptr; ra.nodes8 = nullptr; ra.node_box = nullptr; ra.level_nodes = nullptr;
     ra.pad = pad; ra.reach = reach; ra.sphere_slack2 = sphere_slack2; ra.n_prims = n;
     hipLaunchKernelGGL(refit_prims_kernel, grid(nP), dim3(kRefitBlock), 0, st, ra);
+    if (unless_large_triangles && nt) {
+        // the caller left the builder open: a scene with triangles the host builder would cut into references is the host's
+        const float ext_max = std::max(std::max(ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1]), ctx->scene_hi[2] - ctx->scene_lo[2]);
+        uint32_t large = 0;
+        PT_HIP(ctx, hipMemsetAsync(d.totals, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(count_large_kernel, grid(nt), dim3(kBuildBlock), 0, st, d.box, nS, n, ext_max / 16.0f, reinterpret_cast<uint32_t *>(d.totals));
+        PT_HIP(ctx, hipMemcpyAsync(&large, d.totals, sizeof large, hipMemcpyDeviceToHost, st));
+        PT_HIP(ctx, hipStreamSynchronize(st));
+        if (large) return kDeviceBuildFallback;
+    }
     MortonGrid mg;
     for (int k = 0; k < 3; k++) {
         mg.lo[k] = ctx->scene_lo[k];
@@ -685,7 +695,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         // ---- the two-child tree, top-down by SAH (pt_build_sah.hpp)
         uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
         PT_HIP(ctx, hipMemcpyAsync(d.bounds, init, sizeof init, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(sah_bounds_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[0], d.cl_hi[0], n, d.bounds);
+        hipLaunchKernelGGL(sah_bounds_kernel, dim3((unsigned)wave_chunk_blocks(nP)), dim3(kBuildBlock), 0, st, d.cl_lo[0], d.cl_hi[0], n, d.bounds);
         PT_HIP(ctx, hipMemcpyAsync(init, d.bounds, sizeof init, hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipMemsetAsync(d.bn_hi, 0, tree_cap * sizeof(float4), st));          // numbers never given out hold no primitives
         PT_HIP(ctx, hipStreamSynchronize(st));
@@ -707,14 +717,16 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         while (n_act > 0) {
             if (level >= kDeviceBuildMaxLevels || (size_t)node_base + 2 * (size_t)n_act + nP > tree_cap) return kDeviceBuildFallback;
             const SahRange *act = d.act[level & 1];
+            hipLaunchKernelGGL(sah_fill_centres_kernel, grid((size_t)n_act * 6), dim3(kBuildBlock), 0, st, d.centres, n_act * 6);
+            hipLaunchKernelGGL(sah_centres_kernel, dim3((unsigned)wave_chunk_blocks(nP)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres);
             hipLaunchKernelGGL(sah_fill_kernel, grid((size_t)n_act * kSahBinWords), dim3(kBuildBlock), 0, st, d.bins, (size_t)n_act * kSahBinWords);
-            hipLaunchKernelGGL(sah_bin_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.bins);
+            hipLaunchKernelGGL(sah_bin_kernel, dim3((unsigned)((nP + (size_t)kBinChunk * (kBuildBlock / 64) - 1) / ((size_t)kBinChunk * (kBuildBlock / 64)))), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres, d.bins);
             hipLaunchKernelGGL(sah_split_kernel, grid((size_t)n_act), dim3(kBuildBlock), 0, st, act, n_act, d.bins, node_base, tree, d.split, d.cand, d.flags);
             size_t bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)(2 * n_act), rocprim::plus<uint64_t>(), st));
             hipLaunchKernelGGL(sah_next_kernel, grid((size_t)(2 * n_act)), dim3(kBuildBlock), 0, st, d.cand, 2 * n_act, d.flags, d.offs, d.act[(level + 1) & 1], d.small, n_small, d.slot,
                                d.totals);
-            hipLaunchKernelGGL(sah_side_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left);
+            hipLaunchKernelGGL(sah_side_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.centres, d.split, left);
             bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, left, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(sah_partition_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left, rank, d.slot, d.cl_lo[cur ^ 1],
@@ -932,7 +944,7 @@ int rebuild_scene(pt_context *ctx)
 #if !defined(PT_NODES_SOA) && !defined(PT_NODES_3LOAD)
     if (groups.empty() && ctx->bvh_width == 4 &&
         (ctx->tree_build == 1 || ctx->tree_build == 3 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
-        const int rc = build_scene_on_device(ctx, obj_first_tri, nt);
+        const int rc = build_scene_on_device(ctx, obj_first_tri, nt, ctx->tree_build == 2 && ctx->split_budget > 0.0f);
         if (rc != kDeviceBuildFallback) return rc;
     }
 #endif
