@@ -20,6 +20,9 @@ def main():
     for inst in (int(x) for x in os.environ.get("INST", "0 1 2").split()):
         with pa.PathTracer(0) as tr:
             tr.set_option("instancing", inst)
+            # the host builder, so that the three modes are compared on what they do with shared meshes (by default the
+            # device builds this scene flat, in less time than the host needs for the one shared mesh: TREE_BUILD=2)
+            tr.set_option("tree_build", int(os.environ.get("TREE_BUILD", "0")))
             t0 = time.time()
             tr.load_scene(scene, sky); tr.resize(W, H)
             p = pa.make_params(scene, W, H, seed=0.5, spp=spp, max_bounces=8)
