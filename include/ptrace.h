@@ -178,14 +178,15 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                from the exact one by a relative RMSE below 5e-3 (measured 7e-4 to 1.6e-3); +3 % to +11 % rays per second.
  *                The only option that changes the image.
  *   "tree_build"  Who builds the tree over whatever is not a copy of a shared mesh ("instancing").  0: the host's
- *                binned-SAH builder (sixteen threads: 75 ms for 262 k triangles, 4.3 s for ten million).  1: the device -
- *                Morton sort, top-down binned SAH (levels over the whole array while a node has more than 128
- *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 7 ms and 90 ms for the
- *                same scenes, node visits per ray within 5 % of the host tree's (rays per second 0.97x - 1.03x).
- *                2 (default): the device from two million primitives on, the host below.  3: the device, with the
- *                two-child tree made by locally-ordered clustering from the leaves up - a quarter of the build time
- *                again (22 ms for ten million), a fifth more node visits per ray.  Four-child tree only; a tree too
- *                deep for a lane's traversal stack is handed to the host builder.
+ *                binned-SAH builder (sixteen threads: 75-95 ms for 262 k triangles, 4.3 s for ten million).  1: the device -
+ *                Morton sort, the same top-down binned SAH (passes over the whole array while a node has more than 128
+ *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 7 ms and 49 ms for the
+ *                same scenes, and the same tree quality (14.96 against 14.97 node visits per ray on the first).
+ *                2 (default): the device for scenes of 16 384 primitives or more, unless they hold triangles the host
+ *                builder would cut into references ("split_percent"; the device builders do not cut) - then, and below
+ *                that size, the host.  3: the device, with the two-child tree made by locally-ordered clustering from
+ *                the leaves up - half the build time again (21 ms for ten million), a fifth more node visits per ray.
+ *                Four-child tree only; a tree too deep for a lane's traversal stack is handed to the host builder.
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most
  *                n blocks per compute unit, which leaves room for another context's dispatch to run alongside
  *                (two eyes of a stereo pair on one GPU: 2 each).
@@ -202,8 +203,10 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                2 (default): the shared mesh is built ONCE on the host, as a tree over its object-space triangles;
  *                the device makes a copy of that tree per object and refits each copy under its object's matrix.
  *                What the kernels walk is an ordinary flattened world-space tree (any backend, any localToWorld),
- *                at the flattened tree's speed, that the host never built: 38 copies of 262 k triangles in 76 ms
- *                instead of 4.2 s, and pt_update_transforms refits it like any flattened scene (1 ms there).
+ *                at the flattened tree's speed, that the host never built: 38 copies of 262 k triangles in 82 ms
+ *                instead of 4.2 s, and pt_update_transforms refits it like any flattened scene (1 ms there).  When
+ *                the shared meshes add up to more than a sixtieth of the scene and "tree_build" allows it, the whole
+ *                scene is built flat on the device instead, which is then quicker (that scene: 50 ms).
  *                1: the objects - if placed by rotation or mirror x uniform scale + translation; sheared or unevenly
  *                scaled ones are flattened - share ONE tree on the device too, under a top-level tree with a box per
  *                object; triangle tests still run on world-space vertices transformed as the shader transforms them.
