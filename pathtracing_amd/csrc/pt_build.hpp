@@ -8,12 +8,14 @@
 //   2. a record and a padded box per primitive (build_prims_kernel, then refit_prims_kernel - the same kernel and therefore
 //      the same boxes as a transform update);
 //   3. 63-bit Morton codes of the box centres and a radix sort (rocPRIM);
-//   4. the two-child tree by parallel locally-ordered clustering (Meister and Bittner, "Parallel locally-ordered
-//      clustering for bounding volume hierarchy construction", IEEE TVCG 24(3), 2018): every cluster looks kPlocRadius
-//      places to either side in the sorted order for the neighbour whose union with it has the smallest area, pairs that
-//      chose each other merge, the survivors are compacted, until one cluster is left - bottom-up, a few dozen rounds;
+//   4. the two-child tree: top-down by binned SAH (pt_build_sah.hpp; the default), or - option tree_build 3 - by parallel
+//      locally-ordered clustering (Meister and Bittner, "Parallel locally-ordered clustering for bounding volume hierarchy
+//      construction", IEEE TVCG 24(3), 2018; the ploc_* kernels below): every cluster looks kPlocRadius places to either side in
+//      the sorted order for the neighbour whose union with it has the smallest area, pairs that chose each other merge, the
+//      survivors are compacted - bottom-up, a few dozen rounds - and the host's SAH builder makes the top of the tree over the
+//      last few thousand clusters;
 //   5. the collapse to four children per node level by level from the root (open the inner child of largest area, as
-//      bvh.cpp does), which numbers the nodes and the records breadth first;
+//      bvh.cpp does), then a depth-first renumbering of nodes and records;
 //   6. the node boxes and their quantisation from the leaves up (refit_nodes_kernel), level by level.
 // Everything is a function of the input alone: neighbours tie-break by position, places are given out by prefix sums, never
 // by atomic counters, so two builds of one scene give the same tree.  The closest hit does not depend on the tree at all.
@@ -161,20 +163,41 @@ __global__ __launch_bounds__(kBuildBlock) void build_prims_kernel(const BuildSce
     prims[(size_t)p * 3 + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// How many triangles the host builder would consider cutting into several references (bvh.cpp, split_references: a box
-// that spans a sixteenth of the scene's largest extent).  The device builders do not cut; when the caller leaves the choice
-// of builder open, a scene with such triangles goes to the host's.
-__global__ __launch_bounds__(kBuildBlock) void count_large_kernel(const float *box, int first, int n, float threshold, uint32_t *count)
+// ---- reference splitting (bvh.hpp, split_references) in a device build.  Which triangles are cut, how often and where is
+// the host's code and the host's arithmetic - they are few: only a triangle whose box spans a sixteenth of the scene is a
+// candidate.  The device names the candidates (list_large_kernel, with a margin: the host applies its own rule again), the
+// host cuts them and sends back one (reference, primitive, cut box) entry per piece; the first piece takes the primitive's
+// own place, the others are appended behind the primitives.  From there on the build works on references: refit_prims_kernel
+// clips a reference's box to its cut, several records name one triangle, and a later refit keeps the cuts of objects that
+// did not move - all as after a host build.
+__global__ __launch_bounds__(kBuildBlock) void list_large_kernel(const float *box, int first, int n, float threshold, uint32_t *list, uint32_t *count)
 {
     const int p = first + blockIdx.x * kBuildBlock + threadIdx.x;
-    bool large = false;
-    if (p < n) {
-        const float *b = box + (size_t)p * 6;
-        const float e = fmaxf(fmaxf(b[3] - b[0], b[4] - b[1]), b[5] - b[2]);
-        large = e >= threshold && e < kHugeCoord;       // (a NaN or huge coordinate is not cut either)
+    if (p >= n) return;
+    const float *b = box + (size_t)p * 6;
+    const float e = fmaxf(fmaxf(b[3] - b[0], b[4] - b[1]), b[5] - b[2]);
+    if (e >= threshold && e < kHugeCoord) list[atomicAdd(count, 1u)] = (uint32_t)p;      // the host sorts the list: its order is nobody's business
+}
+
+// clip[slot]: the part of its triangle's box a reference stands for (lo.xyz, hi.xyz); everything for a reference that is the
+// whole triangle.
+__global__ __launch_bounds__(kBuildBlock) void fill_clip_kernel(float *clip, size_t n)
+{
+    const size_t s = (size_t)blockIdx.x * kBuildBlock + threadIdx.x;
+    if (s >= n) return;
+    for (int k = 0; k < 3; k++) { clip[s * 6 + k] = -PT_INF; clip[s * 6 + 3 + k] = PT_INF; }
+}
+
+__global__ __launch_bounds__(kBuildBlock) void apply_split_kernel(const int2 *entry, const float *cut, int n_entries, int4 *src, float4 *prims, float *clip)
+{
+    const int j = blockIdx.x * kBuildBlock + threadIdx.x;
+    if (j >= n_entries) return;
+    const int r = entry[j].x, p = entry[j].y;
+    if (r != p) {
+        src[r] = src[p];
+        for (int k = 0; k < 3; k++) prims[(size_t)r * 3 + k] = prims[(size_t)p * 3 + k];      // the id; the rest is refit_prims_kernel's
     }
-    const unsigned long long m = __ballot(large);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
+    for (int k = 0; k < 6; k++) clip[(size_t)r * 6 + k] = cut[(size_t)j * 6 + k];
 }
 
 __device__ __forceinline__ uint64_t spread21(uint32_t v)      // bit i of v to bit 3 i
@@ -563,7 +586,7 @@ __global__ __launch_bounds__(kBuildBlock) void tree_cost_kernel(const float *nod
 
 // The records in tree order: what build_prims_kernel and refit_prims_kernel made per primitive, moved to its slot.
 __global__ __launch_bounds__(kBuildBlock) void build_gather_kernel(const uint32_t *slot_prim, int n, const int4 *src_in, const float4 *prims_in, const float *box_in,
-                                                                   int4 *src, float4 *prims, float *box)
+                                                                   const float *clip_in, int4 *src, float4 *prims, float *box, float *clip)
 {
     const int s = blockIdx.x * kBuildBlock + threadIdx.x;
     if (s > n) return;
@@ -576,12 +599,8 @@ __global__ __launch_bounds__(kBuildBlock) void build_gather_kernel(const uint32_
     src[s] = src_in[p];
     for (int k = 0; k < 3; k++) prims[(size_t)s * 3 + k] = prims_in[(size_t)p * 3 + k];
     for (int k = 0; k < 6; k++) box[(size_t)s * 6 + k] = box_in[(size_t)p * 6 + k];
-}
-
-__global__ __launch_bounds__(kBuildBlock) void build_iota_kernel(int32_t *dst, int first, int count)
-{
-    const int t = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (t < count) dst[t] = first + t;
+    if (clip_in)
+        for (int k = 0; k < 6; k++) clip[(size_t)s * 6 + k] = clip_in[(size_t)p * 6 + k];
 }
 
 }  // namespace ptrace

@@ -10,14 +10,15 @@
 //   node's primitives one contiguous, still Morton-ordered range):
 //     sah_centres_kernel    the bounds of the box centres of every node's primitives: the range its bins are laid over
 //     sah_bin_kernel        every primitive of a node with more than kSahSmall adds its box to one of 32 bins per axis of
-//                           its node (by its centre's place among the node's centres); a block first collects, in LDS, what goes
-//                           to the node of its first primitive - near the root that is everything
+//                           its node (by its centre's place among the node's centres); a wave collects in LDS bins of its
+//                           own what goes to the node it is in, and sends them on when it comes to the next node
 //     sah_split_kernel      per node: the cheapest of the 93 bin boundaries, area(left) n_left + area(right) n_right; the
 //                           two children get numbers, boxes (exact: unions of bins) and ranges
 //     sah_next_kernel       children with more than kSahSmall primitives form the next level, the others go on a list
 //     sah_side_kernel, scan, sah_partition_kernel   left primitives to the front of the node's range, order kept
 //   lower levels: sah_small_kernel, one wave per listed node, builds the whole subtree of its <= kSahSmall primitives in LDS
-//   by the same rule - no global traffic but the primitives in and the nodes out.
+//   by the same rule (ranges of kSahExhaustive or fewer: by trying every split) - no global traffic but the primitives in
+//   and the nodes out.
 // Min, max and integer add commute exactly, so the bins - and the tree - do not depend on the order the atomics land in.
 #pragma once
 

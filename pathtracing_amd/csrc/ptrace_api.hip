@@ -525,14 +525,14 @@ struct DeviceArena {
 // The scene as pt_set_spheres / pt_set_meshes left it, every mesh object flattened (RayTracingShader.compute:236-240 applied
 // once instead of per ray), as a four-wide tree made on the device.  The host touches the objects and the spheres, never a
 // triangle.  Leaves the context exactly as the host build of a flat scene does, minus the two-child tree.
-int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt, bool unless_large_triangles)
+int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const int nS = (int)ctx->spheres.size();
     const size_t nO = ctx->objects.size();
     const size_t nP = (size_t)nS + nt;
     if (nP < 2 || nP >= (1u << 27)) return kDeviceBuildFallback;
-    const int n = (int)nP;
+    int n = (int)nP;                   // references: the primitives, plus the extra pieces of cut triangles (below)
     int rc;
     // ---- inputs: geometry and matrices stay on the device for refits, the rest lives in the arena
     std::vector<int4> otab(nO + 1);
@@ -559,8 +559,8 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     if ((rc = upload(ctx, ctx->d_sphere_mat, smat.data(), smat.size() * sizeof(float4)))) return rc;
 
     struct Parts {
-        int32_t *indices; int4 *objects; uint32_t *bounds;
-        int4 *src; float4 *prims; float *box;
+        int32_t *indices; int4 *objects; uint32_t *bounds, *large;
+        int4 *src; float4 *prims; float *box, *clip; int2 *cut_entry; float *cut_box;
         uint64_t *keys[2]; uint32_t *vals[2];
         float4 *cl_lo[2], *cl_hi[2]; int32_t *nn; uint64_t *flags, *offs, *totals;
         int2 *bn_child; float4 *bn_lo, *bn_hi;
@@ -570,41 +570,20 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         SahRange *act[2], *cand, *small; int32_t *slot; int4 *split; uint32_t *bins, *centres;
         char *temp;
     } d{};
-    size_t sort_bytes = 0, scan_bytes = 0;
-    {
-        uint64_t *k = nullptr; uint32_t *v = nullptr;
-        PT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, (size_t)n, 0u, 63u, ctx->stream));
-        PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, k, k, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
-    }
-    size_t scan32_bytes = 0;
-    {
-        uint32_t *v = nullptr;
-        PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan32_bytes, v, v, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
-    }
-    const size_t temp_bytes = std::max(std::max(sort_bytes, scan_bytes), scan32_bytes) + 256;
-    const size_t sah_nodes = nP / kSahSmall + 2;          // nodes of more than kSahSmall primitives one level can hold
-    const size_t tree_cap = 2 * nP + 1024;                // two-child node numbers (the top-down build leaves gaps in them)
     const size_t n_bounds = 6 * (nO + 1);
-    auto layout = [&](DeviceArena &a) {
-        a.take(d.indices, ctx->indices.size()); a.take(d.objects, nO + 1); a.take(d.bounds, n_bounds);
+    // the first arena: what it takes to know the scene's bounds and its large triangles; the second, once the number of
+    // references is known, holds everything else
+    auto layout_first = [&](DeviceArena &a) {
+        a.take(d.indices, ctx->indices.size()); a.take(d.objects, nO + 1); a.take(d.bounds, n_bounds); a.take(d.large, nP + 1);
         a.take(d.src, nP); a.take(d.prims, nP * 3); a.take(d.box, nP * 6);
-        for (int k = 0; k < 2; k++) { a.take(d.keys[k], nP); a.take(d.vals[k], nP); a.take(d.cl_lo[k], nP); a.take(d.cl_hi[k], nP); a.take(d.items[k], nP); a.take(d.stacked[k], nP); }
-        a.take(d.nn, nP); a.take(d.flags, nP); a.take(d.offs, nP); a.take(d.totals, 32);
-        a.take(d.bn_child, tree_cap); a.take(d.bn_lo, tree_cap); a.take(d.bn_hi, tree_cap);
-        a.take(d.kids, nP); a.take(d.nodes4, nP * 4); a.take(d.slot_prim, nP + 1); a.take(d.slot_prim_dfs, nP + 1); a.take(d.stack_need, 64);
-        a.take(d.below, nP); a.take(d.place, nP);
-        a.take(d.act[0], sah_nodes); a.take(d.act[1], sah_nodes); a.take(d.cand, 2 * sah_nodes); a.take(d.small, nP); a.take(d.slot, 2 * sah_nodes); a.take(d.split, sah_nodes);
-        a.take(d.bins, sah_nodes * kSahBinWords); a.take(d.centres, sah_nodes * 6);
-        a.take(d.temp, temp_bytes);
     };
+    struct Release { char *p = nullptr; ~Release() { if (p) (void)dev_free(p); } } first_arena, second_arena;
     DeviceArena arena;
-    layout(arena);
-    const size_t arena_bytes = arena.used;
-    char *arena_mem = nullptr;
-    PT_HIP(ctx, dev_malloc((void **)&arena_mem, arena_bytes));
-    struct Release { char *p; ~Release() { if (p) (void)dev_free(p); } } release{arena_mem};
-    arena = DeviceArena(); arena.base = arena_mem;
-    layout(arena);
+    layout_first(arena);
+    size_t arena_bytes = arena.used;
+    PT_HIP(ctx, dev_malloc((void **)&first_arena.p, arena_bytes));
+    arena = DeviceArena(); arena.base = first_arena.p;
+    layout_first(arena);
     const auto grid = [](size_t count) { return dim3((unsigned)((count + kBuildBlock - 1) / kBuildBlock)); };
     hipStream_t st = ctx->stream;
 
@@ -615,7 +594,6 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     if (!ctx->indices.empty()) PT_HIP(ctx, hipMemcpyAsync(d.indices, ctx->indices.data(), ctx->indices.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d.objects, otab.data(), otab.size() * sizeof(int4), hipMemcpyHostToDevice, st));
     PT_HIP(ctx, hipMemcpyAsync(d.bounds, bounds.data(), n_bounds * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemsetAsync(d.stack_need, 0, 64 * sizeof(int32_t), st));
     BuildScene bs;
     bs.vertices = ctx->d_vertices; bs.indices = d.indices; bs.matrices = ctx->d_matrices; bs.objects = d.objects; bs.spheres = ctx->d_sphere_mat;
     bs.n_objects = (int32_t)nO; bs.n_spheres = nS; bs.n_tris = (int32_t)nt;
@@ -659,15 +637,104 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     ra.slot_clip = nullptr; ra.build_matrices = nullptr; ra.nodes4 = nullptr; ra.nodes8 = nullptr; ra.node_box = nullptr; ra.level_nodes = nullptr;
     ra.pad = pad; ra.reach = reach; ra.sphere_slack2 = sphere_slack2; ra.n_prims = n;
     hipLaunchKernelGGL(refit_prims_kernel, grid(nP), dim3(kRefitBlock), 0, st, ra);
-    if (unless_large_triangles && nt) {
-        // the caller left the builder open: a scene with triangles the host builder would cut into references is the host's
+    // ---- large triangles: cut into references by the host's split_references (pt_build.hpp, list_large_kernel)
+    std::vector<int2> cut_entry; std::vector<float> cut_box;
+    if (ctx->split_budget > 0.0f && nt) {
         const float ext_max = std::max(std::max(ctx->scene_hi[0] - ctx->scene_lo[0], ctx->scene_hi[1] - ctx->scene_lo[1]), ctx->scene_hi[2] - ctx->scene_lo[2]);
-        uint32_t large = 0;
-        PT_HIP(ctx, hipMemsetAsync(d.totals, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(count_large_kernel, grid(nt), dim3(kBuildBlock), 0, st, d.box, nS, n, ext_max / 16.0f, reinterpret_cast<uint32_t *>(d.totals));
-        PT_HIP(ctx, hipMemcpyAsync(&large, d.totals, sizeof large, hipMemcpyDeviceToHost, st));
+        uint32_t n_large = 0;
+        PT_HIP(ctx, hipMemsetAsync(d.large + nP, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(list_large_kernel, grid(nt), dim3(kBuildBlock), 0, st, d.box, nS, n, 0.99f * (ext_max / 16.0f) - 2.0f * pad, d.large, d.large + nP);
+        PT_HIP(ctx, hipMemcpyAsync(&n_large, d.large + nP, sizeof n_large, hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipStreamSynchronize(st));
-        if (large) return kDeviceBuildFallback;
+        if (n_large) {
+            std::vector<uint32_t> large(n_large);
+            PT_HIP(ctx, hipMemcpyAsync(large.data(), d.large, (size_t)n_large * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PT_HIP(ctx, hipStreamSynchronize(st));
+            std::sort(large.begin(), large.end());
+            std::vector<float> tri9((size_t)n_large * 9);
+            std::vector<Aabb> exact(n_large);
+            for (size_t e = 0; e < n_large; e++) {
+                const uint32_t gid = large[e] - (uint32_t)nS;
+                const size_t o = (size_t)(std::upper_bound(obj_first_tri.begin(), obj_first_tri.begin() + (ptrdiff_t)nO, gid) - obj_first_tri.begin()) - 1;
+                const PtMeshObject &mo = ctx->objects[o];
+                const int32_t *ix = &ctx->indices[(size_t)mo.indices_offset + 3 * (size_t)(gid - obj_first_tri[o])];
+                for (int c = 0; c < 3; c++) {
+                    const float *v = &ctx->vertices[3 * (size_t)ix[c]];
+                    const pt_f3 w = pt_mul_point(mo.local_to_world, pt_make3(v[0], v[1], v[2]));      // RayTracingShader.compute:238-240
+                    tri9[e * 9 + 3 * c] = w.x; tri9[e * 9 + 3 * c + 1] = w.y; tri9[e * 9 + 3 * c + 2] = w.z;
+                }
+                for (int k = 0; k < 3; k++) {
+                    exact[e].lo[k] = std::min(tri9[e * 9 + k], std::min(tri9[e * 9 + 3 + k], tri9[e * 9 + 6 + k]));
+                    exact[e].hi[k] = std::max(tri9[e * 9 + k], std::max(tri9[e * 9 + 3 + k], tri9[e * 9 + 6 + k]));
+                }
+            }
+            // the budget is a share of ALL the scene's triangles (bvh.hpp), the function counts the ones it is given
+            std::vector<uint32_t> ref_tri; std::vector<Aabb> ref_box;
+            split_references(tri9.data(), exact.data(), n_large, ctx->scene_lo, ctx->scene_hi, ctx->split_budget * (float)nt / (float)n_large, ref_tri, ref_box);
+            std::vector<uint32_t> pieces(n_large, 0);
+            for (uint32_t t : ref_tri) pieces[t]++;
+            std::vector<uint32_t> seen(n_large, 0);
+            size_t extra = 0;
+            for (size_t j = 0; j < ref_tri.size(); j++) {
+                const uint32_t e = ref_tri[j];
+                if (pieces[e] < 2) continue;                                  // not cut: the reference is the triangle
+                const int r = seen[e]++ == 0 ? (int)large[e] : (int)(nP + extra++);
+                cut_entry.push_back(make_int2(r, (int)large[e]));
+                for (int k = 0; k < 3; k++) cut_box.push_back(ref_box[j].lo[k]);
+                for (int k = 0; k < 3; k++) cut_box.push_back(ref_box[j].hi[k]);
+            }
+            if (nP + extra >= (1u << 27)) return kDeviceBuildFallback;
+            n = (int)(nP + extra);
+        }
+    }
+    const size_t nR = (size_t)n;
+    const bool cut = !cut_entry.empty();
+
+    // ---- the second arena
+    size_t sort_bytes = 0, scan_bytes = 0, scan32_bytes = 0;
+    {
+        uint64_t *k = nullptr; uint32_t *v = nullptr;
+        PT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, nR, 0u, 63u, ctx->stream));
+        PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, k, k, (uint64_t)0, nR, rocprim::plus<uint64_t>(), ctx->stream));
+        PT_HIP(ctx, rocprim::exclusive_scan(nullptr, scan32_bytes, v, v, 0u, nR, rocprim::plus<uint32_t>(), ctx->stream));
+    }
+    const size_t temp_bytes = std::max(std::max(sort_bytes, scan_bytes), scan32_bytes) + 256;
+    const size_t sah_nodes = nR / kSahSmall + 2;          // nodes of more than kSahSmall references one level can hold
+    const size_t tree_cap = 2 * nR + 1024;                // two-child node numbers (the top-down build leaves gaps in them)
+    auto layout_second = [&](DeviceArena &a) {
+        if (cut) { a.take(d.src, nR); a.take(d.prims, nR * 3); a.take(d.box, nR * 6); a.take(d.clip, nR * 6); a.take(d.cut_entry, cut_entry.size()); a.take(d.cut_box, cut_box.size()); }
+        for (int k = 0; k < 2; k++) { a.take(d.keys[k], nR); a.take(d.vals[k], nR); a.take(d.cl_lo[k], nR); a.take(d.cl_hi[k], nR); a.take(d.items[k], nR); a.take(d.stacked[k], nR); }
+        a.take(d.nn, nR); a.take(d.flags, nR); a.take(d.offs, nR); a.take(d.totals, 32);
+        a.take(d.bn_child, tree_cap); a.take(d.bn_lo, tree_cap); a.take(d.bn_hi, tree_cap);
+        a.take(d.kids, nR); a.take(d.nodes4, nR * 4); a.take(d.slot_prim, nR + 1); a.take(d.slot_prim_dfs, nR + 1); a.take(d.stack_need, 64);
+        a.take(d.below, nR); a.take(d.place, nR);
+        a.take(d.act[0], sah_nodes); a.take(d.act[1], sah_nodes); a.take(d.cand, 2 * sah_nodes); a.take(d.small, nR); a.take(d.slot, 2 * sah_nodes); a.take(d.split, sah_nodes);
+        a.take(d.bins, sah_nodes * kSahBinWords); a.take(d.centres, sah_nodes * 6);
+        a.take(d.temp, temp_bytes);
+    };
+    {
+        const Parts first = d;                             // (a dry run of the layout overwrites the pointers it hands out)
+        arena = DeviceArena();
+        layout_second(arena);
+        arena_bytes += arena.used;
+        PT_HIP(ctx, dev_malloc((void **)&second_arena.p, arena.used));
+        d = first;
+        arena = DeviceArena(); arena.base = second_arena.p;
+        layout_second(arena);
+    }
+    PT_HIP(ctx, hipMemsetAsync(d.stack_need, 0, 64 * sizeof(int32_t), st));
+    if (cut) {
+        // records and boxes again, now per reference: the primitives' as before, the extra pieces' copied from their
+        // primitive, every cut piece's box clipped to its cut (refit_prims_kernel, slot_clip)
+        hipLaunchKernelGGL(build_prims_kernel, grid(nP), dim3(kBuildBlock), 0, st, bs, d.src, d.prims);
+        hipLaunchKernelGGL(fill_clip_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.clip, nR);
+        PT_HIP(ctx, hipMemcpyAsync(d.cut_entry, cut_entry.data(), cut_entry.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        PT_HIP(ctx, hipMemcpyAsync(d.cut_box, cut_box.data(), cut_box.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(apply_split_kernel, grid(cut_entry.size()), dim3(kBuildBlock), 0, st, d.cut_entry, d.cut_box, (int)cut_entry.size(), d.src, d.prims, d.clip);
+        ra.slot_src = d.src; ra.prims = d.prims; ra.prim_box = d.box; ra.slot_clip = d.clip; ra.build_matrices = ctx->d_matrices; ra.n_prims = n;
+        hipLaunchKernelGGL(refit_prims_kernel, grid(nR), dim3(kRefitBlock), 0, st, ra);
+        PT_HIP(ctx, hipGetLastError());
+        PT_HIP(ctx, hipStreamSynchronize(st));               // cut_entry and cut_box are read by the copies above
     }
     MortonGrid mg;
     for (int k = 0; k < 3; k++) {
@@ -675,13 +742,13 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         const float ext = ctx->scene_hi[k] - ctx->scene_lo[k];
         mg.scale[k] = ext > 0.0f && std::isfinite(ext) ? 2097152.0f / ext : 0.0f;
     }
-    hipLaunchKernelGGL(build_morton_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.box, n, mg, d.keys[0], d.vals[0]);
+    hipLaunchKernelGGL(build_morton_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.box, n, mg, d.keys[0], d.vals[0]);
     PT_HIP(ctx, hipGetLastError());
     {
         size_t bytes = temp_bytes;
         PT_HIP(ctx, rocprim::radix_sort_pairs(d.temp, bytes, d.keys[0], d.keys[1], d.vals[0], d.vals[1], (size_t)n, 0u, 63u, st));
     }
-    hipLaunchKernelGGL(ploc_init_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.cl_lo[0], d.cl_hi[0]);
+    hipLaunchKernelGGL(ploc_init_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.vals[1], d.box, n, d.cl_lo[0], d.cl_hi[0]);
     PT_HIP(ctx, hipGetLastError());
     std::chrono::steady_clock::time_point t_sorted;
     if (std::getenv("PTRACE_BUILD_TIMING")) PT_HIP(ctx, hipStreamSynchronize(st));
@@ -695,7 +762,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         // ---- the two-child tree, top-down by SAH (pt_build_sah.hpp)
         uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
         PT_HIP(ctx, hipMemcpyAsync(d.bounds, init, sizeof init, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(sah_bounds_kernel, dim3((unsigned)wave_chunk_blocks(nP)), dim3(kBuildBlock), 0, st, d.cl_lo[0], d.cl_hi[0], n, d.bounds);
+        hipLaunchKernelGGL(sah_bounds_kernel, dim3((unsigned)wave_chunk_blocks(nR)), dim3(kBuildBlock), 0, st, d.cl_lo[0], d.cl_hi[0], n, d.bounds);
         PT_HIP(ctx, hipMemcpyAsync(init, d.bounds, sizeof init, hipMemcpyDeviceToHost, st));
         PT_HIP(ctx, hipMemsetAsync(d.bn_hi, 0, tree_cap * sizeof(float4), st));          // numbers never given out hold no primitives
         PT_HIP(ctx, hipStreamSynchronize(st));
@@ -707,7 +774,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         uint32_t *left = reinterpret_cast<uint32_t *>(d.nn), *rank = reinterpret_cast<uint32_t *>(d.stacked[0]);
         if (n > kSahSmall) {
             PT_HIP(ctx, hipMemcpyAsync(d.act[0], &whole, sizeof whole, hipMemcpyHostToDevice, st));
-            PT_HIP(ctx, hipMemsetAsync(seg[0], 0, nP * sizeof(int32_t), st));
+            PT_HIP(ctx, hipMemsetAsync(seg[0], 0, nR * sizeof(int32_t), st));
             n_act = 1;
         } else {
             PT_HIP(ctx, hipMemcpyAsync(d.small, &whole, sizeof whole, hipMemcpyHostToDevice, st));
@@ -715,27 +782,27 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         }
         PT_HIP(ctx, hipStreamSynchronize(st));               // `whole` and `init` are on the stack
         while (n_act > 0) {
-            if (level >= kDeviceBuildMaxLevels || (size_t)node_base + 2 * (size_t)n_act + nP > tree_cap) return kDeviceBuildFallback;
+            if (level >= kDeviceBuildMaxLevels || (size_t)node_base + 2 * (size_t)n_act + nR > tree_cap) return kDeviceBuildFallback;
             const SahRange *act = d.act[level & 1];
             hipLaunchKernelGGL(sah_fill_centres_kernel, grid((size_t)n_act * 6), dim3(kBuildBlock), 0, st, d.centres, n_act * 6);
-            hipLaunchKernelGGL(sah_centres_kernel, dim3((unsigned)wave_chunk_blocks(nP)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres);
+            hipLaunchKernelGGL(sah_centres_kernel, dim3((unsigned)wave_chunk_blocks(nR)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres);
             hipLaunchKernelGGL(sah_fill_kernel, grid((size_t)n_act * kSahBinWords), dim3(kBuildBlock), 0, st, d.bins, (size_t)n_act * kSahBinWords);
-            hipLaunchKernelGGL(sah_bin_kernel, dim3((unsigned)((nP + (size_t)kBinChunk * (kBuildBlock / 64) - 1) / ((size_t)kBinChunk * (kBuildBlock / 64)))), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres, d.bins);
+            hipLaunchKernelGGL(sah_bin_kernel, dim3((unsigned)((nR + (size_t)kBinChunk * (kBuildBlock / 64) - 1) / ((size_t)kBinChunk * (kBuildBlock / 64)))), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres, d.bins);
             hipLaunchKernelGGL(sah_split_kernel, grid((size_t)n_act), dim3(kBuildBlock), 0, st, act, n_act, d.bins, node_base, tree, d.split, d.cand, d.flags);
             size_t bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)(2 * n_act), rocprim::plus<uint64_t>(), st));
             hipLaunchKernelGGL(sah_next_kernel, grid((size_t)(2 * n_act)), dim3(kBuildBlock), 0, st, d.cand, 2 * n_act, d.flags, d.offs, d.act[(level + 1) & 1], d.small, n_small, d.slot,
                                d.totals);
-            hipLaunchKernelGGL(sah_side_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.centres, d.split, left);
+            hipLaunchKernelGGL(sah_side_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.centres, d.split, left);
             bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, left, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-            hipLaunchKernelGGL(sah_partition_kernel, grid(nP), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left, rank, d.slot, d.cl_lo[cur ^ 1],
+            hipLaunchKernelGGL(sah_partition_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left, rank, d.slot, d.cl_lo[cur ^ 1],
                                d.cl_hi[cur ^ 1], seg[cur ^ 1]);
             uint64_t tot = 0;
             PT_HIP(ctx, hipMemcpyAsync(&tot, d.totals, sizeof tot, hipMemcpyDeviceToHost, st));
             PT_HIP(ctx, hipStreamSynchronize(st));
             node_base += 2 * n_act; n_small += (int)(tot >> 32); n_act = (int)(uint32_t)tot;
-            if ((size_t)n_act > sah_nodes - 2 || (size_t)n_small > nP) return fail(ctx, PT_ERR_HIP, "device tree build: more ranges than primitives");
+            if ((size_t)n_act > sah_nodes - 2 || (size_t)n_small > nR) return fail(ctx, PT_ERR_HIP, "device tree build: more ranges than primitives");
             cur ^= 1; level++;
         }
         rounds = level;
@@ -853,7 +920,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         level_base.push_back(nodes_done); level_count.push_back(items);
         nodes_done += items; recs_done += (int)(tot >> 32);
         items = (int)(uint32_t)tot; side ^= 1;
-        if ((size_t)nodes_done + (size_t)items > nP) return fail(ctx, PT_ERR_HIP, "device tree build: more nodes than primitives");
+        if ((size_t)nodes_done + (size_t)items > nR) return fail(ctx, PT_ERR_HIP, "device tree build: more nodes than primitives");
     }
     if (recs_done != n) return fail(ctx, PT_ERR_HIP, "device tree build: the collapse lost a primitive");
     int32_t stack_need = 0;
@@ -865,9 +932,15 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
 
     // ---- the arrays the kernels read: records in tree order, nodes, boxes from the leaves up
     PT_HIP(ctx, dev_malloc((void **)&ctx->d_nodes4, (size_t)n4 * sizeof(Bvh4Node)));
-    PT_HIP(ctx, dev_malloc((void **)&ctx->d_prims, (nP + 1) * 3 * sizeof(float4)));
-    PT_HIP(ctx, dev_malloc((void **)&ctx->d_slot_src, (nP + 1) * sizeof(int4)));
-    PT_HIP(ctx, dev_malloc((void **)&ctx->d_prim_box, (nP + 1) * 6 * sizeof(float)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_prims, (nR + 1) * 3 * sizeof(float4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_slot_src, (nR + 1) * sizeof(int4)));
+    PT_HIP(ctx, dev_malloc((void **)&ctx->d_prim_box, (nR + 1) * 6 * sizeof(float)));
+    if (cut) {
+        // what a later refit needs to keep the cuts of objects that have not moved (pt_refit.hpp, slot_clip)
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_slot_clip, (nR + 1) * 6 * sizeof(float)));
+        PT_HIP(ctx, dev_malloc((void **)&ctx->d_build_matrices, std::max<size_t>(1, nO) * 16 * sizeof(float)));
+        PT_HIP(ctx, hipMemcpyAsync(ctx->d_build_matrices, ctx->d_matrices, nO * 16 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     PT_HIP(ctx, dev_malloc((void **)&ctx->d_node_box, (size_t)n4 * 6 * sizeof(float)));
     PT_HIP(ctx, dev_malloc((void **)&ctx->d_level_nodes, (size_t)n4 * sizeof(int32_t)));
     ctx->level_first.assign(1, 0);
@@ -885,7 +958,9 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
             hipLaunchKernelGGL(reorder_place_kernel, grid((size_t)ro.count), dim3(kBuildBlock), 0, st, ro);
         }
     }
-    hipLaunchKernelGGL(build_gather_kernel, grid(nP + 1), dim3(kBuildBlock), 0, st, d.slot_prim_dfs, n, d.src, d.prims, d.box, ctx->d_slot_src, ctx->d_prims, ctx->d_prim_box);
+    hipLaunchKernelGGL(build_gather_kernel, grid(nR + 1), dim3(kBuildBlock), 0, st, d.slot_prim_dfs, n, d.src, d.prims, d.box, cut ? d.clip : nullptr, ctx->d_slot_src, ctx->d_prims,
+                       ctx->d_prim_box, ctx->d_slot_clip);
+    ra.slot_clip = ctx->d_slot_clip; ra.build_matrices = ctx->d_build_matrices;
     ra.slot_src = ctx->d_slot_src; ra.prims = ctx->d_prims; ra.prim_box = ctx->d_prim_box; ra.nodes4 = ctx->d_nodes4; ra.node_box = ctx->d_node_box; ra.level_nodes = ctx->d_level_nodes;
     for (size_t l = 0; l + 1 < ctx->level_first.size(); l++) {
         const int first = ctx->level_first[l], count = ctx->level_first[l + 1] - first;
@@ -898,14 +973,14 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
     ctx->walk8 = false; ctx->n_nodes8 = 0; ctx->stack_need8 = 0;
     ctx->n_nodes4 = n4; ctx->n_nodes = n4;                // no two-child tree: n_nodes only says "there is a tree"
-    ctx->n_prims = n; ctx->n_slots = n; ctx->n_top_records = n; ctx->n_spheres = nS;
+    ctx->n_prims = (int)nP; ctx->n_slots = n; ctx->n_top_records = n; ctx->n_spheres = nS;
     ctx->stack_need4 = stack_need;
-    ctx->stats.bvh_nodes = n4; ctx->stats.bvh_prims = n; ctx->stats.bvh_depth = levels;
+    ctx->stats.bvh_nodes = n4; ctx->stats.bvh_prims = (int)nP; ctx->stats.bvh_depth = levels;
     ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("PTRACE_BUILD_TIMING")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "scene build on the device: %d primitives, %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; upload + bounds %.1f ms, "
-                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", n, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
+        std::fprintf(stderr, "scene build on the device: %d primitives, %d references, %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; upload + bounds %.1f ms, "
+                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", (int)nP, n, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
                      ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()));
     }
     ctx->scene_dirty = false;
@@ -953,7 +1028,7 @@ int rebuild_scene(pt_context *ctx)
     }
     if (flat_is_quicker && ctx->bvh_width == 4 &&
         (ctx->tree_build == 1 || ctx->tree_build == 3 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
-        const int rc = build_scene_on_device(ctx, obj_first_tri, nt, ctx->tree_build == 2 && ctx->split_budget > 0.0f);
+        const int rc = build_scene_on_device(ctx, obj_first_tri, nt);
         if (rc != kDeviceBuildFallback) return rc;
     }
 #endif

@@ -54,8 +54,8 @@ def test_device_built_tree_gives_the_oracles_image(build, name, capfd, monkeypat
         assert _same(t.read_result(), want) and (t.read_hit_ids() == want_ids).all()
         first = t.stats()
         log = capfd.readouterr().err
-        m = re.search(r"scene build on the device: (\d+) primitives, (\d+) nodes", log)
-        assert m and int(m.group(1)) == len(s.spheres) + s.n_triangles and int(m.group(2)) == first["bvh_nodes"]     # no fallback to the host
+        m = re.search(r"scene build on the device: (\d+) primitives, (\d+) references, (\d+) nodes", log)
+        assert m and int(m.group(1)) == len(s.spheres) + s.n_triangles and int(m.group(3)) == first["bvh_nodes"]     # no fallback to the host
         hit = _tree_equals_loop(t, _rays(np.random.default_rng(5), 4000))
         assert (hit > 0).sum() > 10
         for backend in (1, 2, 0):
@@ -165,6 +165,54 @@ def test_device_build_of_awkward_scenes(build, kind, sky_small):
                     assert _same(moved_image, t.read_result())
     g, c = images[build][0], images[0][0]
     assert ((g.view(np.uint32) == c.view(np.uint32)) | (np.isnan(g) & np.isnan(c))).all() and (images[build][1] == images[0][1]).all()
+
+
+@pytest.mark.parametrize("build", BUILDS)
+def test_device_build_cuts_large_triangles_into_references(build, sky_small, capfd, monkeypatch):
+    """Option "split_percent" in a device build: the device names the wall-sized triangles and long beams, the host's
+    split_references cuts them, and the build works on references - several records naming one triangle, boxes clipped to
+    their cuts.  As after a host build: the oracle's image, ids and ray count at every budget, fewer node visits and
+    primitive tests with cuts than without, the same primitive count; a refit with unchanged matrices keeps every cut (same
+    visit count), a moved beam still equals the oracle and a full build of the moved scene, and the exhaustive ray query -
+    which walks records - reports every triangle once."""
+    from test_gpu_parity import _room_with_beams
+    monkeypatch.setenv("PTRACE_BUILD_TIMING", "1")
+    f, objs, verts, index = _room_with_beams()
+    W, H = 128, 72
+    p = pa.make_params(f, W, H, spp=2, max_bounces=5, seed=0.41, eye=(2.0, 6.0, -13.0), target=(0.0, 4.0, 0.0), fov=60)
+    c, cid, cst = po.Oracle(f.spheres, objs, verts, index, sky=sky_small).render(p, W, H, threads=4)
+    seen = {}
+    with pa.PathTracer(0) as t:
+        t.set_option("instancing", 0); t.set_option("tree_build", build)
+        t.set_spheres(f.spheres); t.set_meshes(objs, verts, index); t.set_sky(sky_small); t.resize(W, H)
+        for percent in (0, 30, 400):
+            t.set_option("split_percent", percent)
+            t.stats(); capfd.readouterr(); t.render(p)
+            st = t.stats()
+            m = re.search(r"scene build on the device: (\d+) primitives, (\d+) references", capfd.readouterr().err)
+            assert m, percent
+            assert (t.read_hit_ids() == cid).all() and _same(t.read_result(), c) and st["rays"] == cst["rays"], percent
+            seen[percent] = (st["nodes_visited"], st["prims_tested"], st["bvh_nodes"], st["bvh_prims"], int(m.group(2)) - int(m.group(1)))
+            _tree_equals_loop(t, _rays(np.random.default_rng(9), 2000, 10.0))
+        nt = int(objs["count"].sum()) // 3                                   # the budget is a share of the scene's triangles
+        assert seen[0][4] == 0 and 0 < seen[30][4] <= 0.3 * nt and seen[30][4] < seen[400][4] <= 4.0 * nt, seen
+        assert seen[0][3] == seen[30][3] == seen[400][3]                     # primitives, not references
+        assert seen[30][2] > seen[0][2] and seen[400][2] > seen[30][2]       # more references, more nodes
+        assert seen[30][0] < 0.85 * seen[0][0] and seen[30][1] < 0.6 * seen[0][1], seen
+        assert seen[400][0] < 0.7 * seen[0][0] and seen[400][1] < 0.2 * seen[0][1], seen
+        t.set_option("split_percent", 30)
+        t.stats(); t.render(p); before = t.stats()["nodes_visited"]
+        t.update_transforms(objs); t.render(p)                                # the same matrices: a refit that keeps every cut
+        assert _same(t.read_result(), c) and t.stats()["nodes_visited"] == before
+        moved = objs.copy()
+        m4 = moved["m"][5].reshape(4, 4).T.copy(); m4[:3, 3] += (1.5, -0.5, 2.0); moved["m"][5] = m4.T.reshape(16)
+        t.update_transforms(moved); t.render(p)
+        c2, cid2, _ = po.Oracle(f.spheres, moved, verts, index, sky=sky_small).render(p, W, H, threads=4)
+        g2 = t.read_result()
+        assert (t.read_hit_ids() == cid2).all() and _same(g2, c2)
+        _tree_equals_loop(t, _rays(np.random.default_rng(10), 2000, 10.0))
+        t.set_option("refit", 0); t.update_transforms(moved); t.render(p)     # a full device build of the moved scene
+        assert _same(t.read_result(), g2)
 
 
 def test_tree_build_option_values():
