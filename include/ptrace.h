@@ -182,9 +182,9 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                Morton sort, the same top-down binned SAH (passes over the whole array while a node has more than 128
  *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 7 ms and 49 ms for the
  *                same scenes, and the same tree quality (14.96 against 14.97 node visits per ray on the first).
- *                2 (default): the device for scenes of 16 384 primitives or more, unless they hold triangles the host
- *                builder would cut into references ("split_percent"; the device builders do not cut) - then, and below
- *                that size, the host.  3: the device, with the two-child tree made by locally-ordered clustering from
+ *                2 (default): the device for scenes of 16 384 primitives or more, the host below.  Large triangles
+ *                are cut into references ("split_percent") in a device build as in a host build.
+ *                3: the device, with the two-child tree made by locally-ordered clustering from
  *                the leaves up - half the build time again (21 ms for ten million), a fifth more node visits per ray.
  *                Four-child tree only; a tree too deep for a lane's traversal stack is handed to the host builder.
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most

@@ -122,7 +122,7 @@ struct pt_context {
     bool flatten_once = false;        // the two-level tree of the last attempt could overflow a lane's stack: build flat
     // option "tree_build": 0 the host's binned-SAH builder; 1 the device builder (pt_build.hpp; top-down SAH, pt_build_sah.hpp) for
     // whatever is not a copy of a shared mesh; 2 (default) the device builder for scenes of kDeviceBuildMinPrims primitives or
-    // more without triangles the host builder would cut into references; 3 the device builder with its two-child tree made by
+    // more; 3 the device builder with its two-child tree made by
     // clustering - half the build time again, a fifth more node visits per ray
     int tree_build = 2;
     bool device_built = false;        // the last build ran on the device: a four-wide tree only, like `expanded`
