@@ -187,6 +187,11 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                3: the device, with the two-child tree made by locally-ordered clustering from
  *                the leaves up - half the build time again (21 ms for ten million), a fifth more node visits per ray.
  *                Four-child tree only; a tree too deep for a lane's traversal stack is handed to the host builder.
+ *   "rebuild_percent"  30 (default): pt_update_transforms refits, which keeps the topology of the last build - after
+ *                large motion the boxes overlap and rays visit more nodes.  The summed node area of a refitted
+ *                device-built tree is taken on the device after every refit and read by a later pt_render without
+ *                waiting for it; when it exceeds the freshly built tree's by this many per cent, that render builds
+ *                anew (on the device: milliseconds).  0: never.  Trees built by the host are only ever refitted.
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most
  *                n blocks per compute unit, which leaves room for another context's dispatch to run alongside
  *                (two eyes of a stereo pair on one GPU: 2 each).

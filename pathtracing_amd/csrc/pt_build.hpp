@@ -562,10 +562,11 @@ __global__ __launch_bounds__(kBuildBlock) void reorder_place_kernel(const Reorde
     a.level_nodes_out[t] = me.x;
 }
 
-// Measurement (PTRACE_BUILD_TIMING): the surface-area cost of the four-wide tree as it lies on the device - the sum over
-// nodes of box area / root area, which is the expected number of node visits of a ray that crosses the root's box at
-// random.  One partial sum per block.
-__global__ __launch_bounds__(kBuildBlock) void tree_cost_kernel(const float *node_box, int n_nodes, float *partial)
+// The surface-area cost of the four-wide tree as it lies on the device: the sum over nodes of box area - divided by the
+// root's (`relative`), the expected number of node visits of a ray that crosses the root's box at random (printed under
+// PTRACE_BUILD_TIMING); as it is, the figure a refitted tree is compared with the freshly built one by (option
+// "rebuild_percent").  One partial sum per block.
+__global__ __launch_bounds__(kBuildBlock) void tree_cost_kernel(const float *node_box, int n_nodes, int relative, float *partial)
 {
     __shared__ float sums[kBuildBlock];
     const int i = blockIdx.x * kBuildBlock + threadIdx.x;
@@ -573,7 +574,8 @@ __global__ __launch_bounds__(kBuildBlock) void tree_cost_kernel(const float *nod
     if (i < n_nodes) {
         const float *b = node_box + (size_t)i * 6, *r = node_box;
         const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2], rx = r[3] - r[0], ry = r[4] - r[1], rz = r[5] - r[2];
-        a = (ex * ey + ey * ez + ez * ex) / (rx * ry + ry * rz + rz * rx);
+        a = ex * ey + ey * ez + ez * ex;
+        if (relative) a /= rx * ry + ry * rz + rz * rx;
     }
     sums[threadIdx.x] = a;
     __syncthreads();

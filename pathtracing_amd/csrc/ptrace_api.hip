@@ -126,6 +126,15 @@ struct pt_context {
     // clustering - half the build time again, a fifth more node visits per ray
     int tree_build = 2;
     bool device_built = false;        // the last build ran on the device: a four-wide tree only, like `expanded`
+    // option "rebuild_percent": a refit keeps the topology of the last build, so large motion leaves boxes that overlap; when
+    // the summed node area of a refitted device-built tree exceeds that of the build by this much, the next render builds
+    // anew (milliseconds on the device).  The sum is taken on the device after every refit and read without waiting.
+    int rebuild_percent = 30;
+    double built_cost = 0.0;          // summed node area right after the last device build
+    float *d_cost = nullptr, *h_cost = nullptr;       // one partial sum per block of tree_cost_kernel; pinned copy
+    size_t cost_blocks = 0;
+    hipEvent_t ev_cost = nullptr;
+    bool cost_pending = false;        // h_cost is being written by the copy ev_cost follows
     float4 *d_inst = nullptr;         // SceneDev::inst
     std::vector<CachedMesh> mesh_cache;
     uint64_t mesh_versions = 0;
@@ -967,7 +976,24 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         hipLaunchKernelGGL(refit_nodes_kernel, grid((size_t)count), dim3(kRefitBlock), 0, st, ra, first, count);
     }
     PT_HIP(ctx, hipGetLastError());
-    PT_HIP(ctx, hipStreamSynchronize(st));               // the arena goes when this returns
+    {
+        // the tree's summed node area, against which refits are measured (option rebuild_percent)
+        const size_t nb = ((size_t)n4 + kBuildBlock - 1) / kBuildBlock;
+        if (nb != ctx->cost_blocks) {
+            free_dev(ctx->d_cost);
+            if (ctx->h_cost) { (void)host_free(ctx->h_cost); ctx->h_cost = nullptr; }
+            ctx->cost_blocks = 0;
+            PT_HIP(ctx, dev_malloc((void **)&ctx->d_cost, nb * sizeof(float)));
+            PT_HIP(ctx, host_malloc((void **)&ctx->h_cost, nb * sizeof(float), hipHostMallocDefault));
+            ctx->cost_blocks = nb;
+        }
+        hipLaunchKernelGGL(tree_cost_kernel, dim3((unsigned)nb), dim3(kBuildBlock), 0, st, ctx->d_node_box, n4, 0, ctx->d_cost);
+        PT_HIP(ctx, hipMemcpyAsync(ctx->h_cost, ctx->d_cost, nb * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    PT_HIP(ctx, hipStreamSynchronize(st));               // the arenas go when this returns
+    ctx->built_cost = 0.0;
+    for (size_t b = 0; b < ctx->cost_blocks; b++) ctx->built_cost += ctx->h_cost[b];
+    ctx->cost_pending = false;
     ctx->device_built = true;
     ctx->refit_ready = ctx->refit != 0 && nO > 0;
     ctx->box_pad = pad; ctx->sphere_slack2 = sphere_slack2;
@@ -1719,6 +1745,13 @@ float reach_needed(const pt_context *ctx, const float *origins, int n, int strid
 int rebuild_scene(pt_context *ctx);
 int ensure_scene(pt_context *ctx, const float *origins, int n, int stride)
 {
+    if (ctx->cost_pending && hipEventQuery(ctx->ev_cost) == hipSuccess) {
+        // what the last refit left of the tree (option rebuild_percent): read when it has arrived, never waited for
+        ctx->cost_pending = false;
+        double cost = 0.0;
+        for (size_t b = 0; b < ctx->cost_blocks; b++) cost += ctx->h_cost[b];
+        if (ctx->device_built && cost > ctx->built_cost * (1.0 + 0.01 * ctx->rebuild_percent)) ctx->scene_dirty = true;
+    }
     if (tree_width(ctx) == 2 && (ctx->bvh2_stale || ctx->n_inst)) ctx->scene_dirty = true;   // the two-child tree is flat and never refitted
     if ((ctx->expanded || ctx->device_built) && ctx->bvh_width != 4) ctx->scene_dirty = true;  // another width: a host build of the flattened scene
     for (int pass = 0; pass < 2; pass++) {
@@ -1906,6 +1939,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_refit, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_cost, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = dev_malloc((void **)&ctx->d_work, kWorkShards * kWorkStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = dev_malloc((void **)&ctx->d_stats, kStatsShards * kStatsStride * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     hipDeviceProp_t prop;
@@ -1988,6 +2022,9 @@ void pt_destroy(pt_context *ctx)
         if (ctx->ev_cams[i]) (void)hipEventDestroy(ctx->ev_cams[i]);
     }
     if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
+    if (ctx->ev_cost) (void)hipEventDestroy(ctx->ev_cost);
+    free_dev(ctx->d_cost);
+    if (ctx->h_cost) (void)host_free(ctx->h_cost);
     free_dev(ctx->wf_state); free_dev(ctx->wf_queues); free_dev(ctx->wf_counters); free_dev(ctx->d_pool_state);
     free_dev(ctx->d_block_cost); free_dev(ctx->d_block_order);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -2106,12 +2143,18 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
     }
     }
     PT_HIP(ctx, hipGetLastError());
+    if (ctx->device_built && ctx->rebuild_percent > 0 && ctx->cost_blocks == ((size_t)ctx->n_nodes4 + kBuildBlock - 1) / kBuildBlock) {
+        hipLaunchKernelGGL(tree_cost_kernel, dim3((unsigned)ctx->cost_blocks), dim3(kBuildBlock), 0, ctx->stream, ctx->d_node_box, ctx->n_nodes4, 0, ctx->d_cost);
+        PT_HIP(ctx, hipMemcpyAsync(ctx->h_cost, ctx->d_cost, ctx->cost_blocks * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipEventRecord(ctx->ev_cost, ctx->stream));
+        ctx->cost_pending = true;
+    }
     if (std::getenv("PTRACE_BUILD_TIMING") && !ctx->walk8 && ctx->n_nodes4 > 0) {
         // node 0 is the root (of the top-level tree when copies hang below it); every node's box is fresh
         const int nb = (ctx->n_nodes4 + kBuildBlock - 1) / kBuildBlock;
         float *d_partial = nullptr;
         PT_HIP(ctx, dev_malloc((void **)&d_partial, (size_t)nb * sizeof(float)));
-        hipLaunchKernelGGL(tree_cost_kernel, dim3((unsigned)nb), dim3(kBuildBlock), 0, ctx->stream, ctx->d_node_box, ctx->n_nodes4, d_partial);
+        hipLaunchKernelGGL(tree_cost_kernel, dim3((unsigned)nb), dim3(kBuildBlock), 0, ctx->stream, ctx->d_node_box, ctx->n_nodes4, 1, d_partial);
         std::vector<float> partial((size_t)nb);
         PT_HIP(ctx, hipMemcpyAsync(partial.data(), d_partial, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2615,6 +2658,11 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         if (value < 0 || value > 2) return fail(ctx, PT_ERR_INVALID, "pt_set_option: instancing must be 0, 1 or 2");
         if (ctx->instancing != value) ctx->scene_dirty = true;
         ctx->instancing = value;
+        return PT_OK;
+    }
+    if (std::strcmp(name, "rebuild_percent") == 0) {
+        if (value < 0 || value > 10000) return fail(ctx, PT_ERR_INVALID, "pt_set_option: rebuild_percent must be 0..10000");
+        ctx->rebuild_percent = value;
         return PT_OK;
     }
     if (std::strcmp(name, "tree_build") == 0) {

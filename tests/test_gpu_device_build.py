@@ -215,6 +215,47 @@ def test_device_build_cuts_large_triangles_into_references(build, sky_small, cap
         assert _same(t.read_result(), g2)
 
 
+def test_refitted_tree_that_has_decayed_is_built_anew(sky_small, capfd, monkeypatch):
+    """Option "rebuild_percent" (default 30): a refit keeps the last build's topology, so three meshes built on top of one
+    another and then pulled apart leave a tree whose every node spans all three.  The summed node area is taken on the device
+    after the refit and read by a later render without waiting; beyond the threshold that render builds anew - on the device,
+    so it costs milliseconds.  Every frame equals the oracle's whether it comes from the refitted or the rebuilt tree; with
+    the option at 0 the tree is only ever refitted."""
+    monkeypatch.setenv("PTRACE_BUILD_TIMING", "1")
+    f = pa.Scene("fixture")
+    objs = np.zeros(3, dtype=f.objects.dtype)
+    for k in range(3):
+        objs[k] = (_rot_y(7.0 * k, (0.05 * k, 0.0, 0.0)), 0, len(f.indices))
+    apart = objs.copy()
+    for k in range(3):
+        apart["m"][k] = _rot_y(7.0 * k, (-9.0 + 9.0 * k, 0.0, 3.0 * k))
+    W, H = 96, 54
+    p = pa.make_params(f, W, H, spp=1, max_bounces=4, seed=0.3, eye=(0, 6, -20), target=(0, 1, 2), fov=60)
+    want, want_ids, _ = po.Oracle(f.spheres, apart, f.vertices, f.indices, sky=sky_small).render(p, W, H, threads=4)
+    last = {}
+    for percent, builds_expected in ((30, 2), (0, 1)):
+        with pa.PathTracer(0) as t:
+            t.set_option("instancing", 0); t.set_option("tree_build", 1); t.set_option("rebuild_percent", percent)
+            t.set_spheres(f.spheres); t.set_meshes(objs, f.vertices, f.indices); t.set_sky(sky_small); t.resize(W, H)
+            capfd.readouterr()
+            t.render(p); t.sync()
+            t.update_transforms(apart)
+            visits = []
+            for frame in range(3):
+                t.stats(); t.render(p); t.sync()
+                assert (t.read_hit_ids() == want_ids).all() and _same(t.read_result(), want), (percent, frame)
+                visits.append(t.stats()["nodes_visited"])
+            builds = len(re.findall(r"scene build on the device", capfd.readouterr().err))
+            assert builds == builds_expected, (percent, builds)
+            last[percent] = visits[-1]
+            if not percent:
+                assert visits[-1] == visits[0]
+    assert last[30] < 0.8 * last[0], last                            # the rebuilt tree is the better one
+    with pa.PathTracer(0) as t:
+        with pytest.raises(Exception):
+            t.set_option("rebuild_percent", -1)
+
+
 def test_tree_build_option_values():
     with pa.PathTracer(0) as t:
         for v in (0, 1, 2, 3):
