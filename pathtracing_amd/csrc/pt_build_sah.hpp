@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBuildBlock) void sah_split_kernel(const SahRange *
     const uint32_t *nb = bins + (size_t)a * kSahBinWords;
     int best_axis = -1, best_bin = 0; float best_cost = PT_INF;
     for (int ax = 0; ax < 3; ax++) {
-        float right_cost[kSahBins];          // right_cost[s]: bins s + 1 .. 15
+        float right_cost[kSahBins];          // right_cost[s]: bins s + 1 .. 31
         SahBox acc; sah_box_reset(acc);
         for (int b = kSahBins - 1; b >= 1; b--) { sah_box_add(acc, nb + (ax * kSahBins + b) * 7); right_cost[b - 1] = acc.n ? sah_box_cost(acc) : PT_INF; }
         sah_box_reset(acc);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
         for (int ax = 0; ax < 3; ax++) { l[ax] = wave_min(l[ax]); h[ax] = wave_max(h[ax]); cl[ax] = wave_min(cl[ax]); ch[ax] = wave_max(ch[ax]); }
         int n_left = 1;
         if (k > 2 && k <= kSahExhaustive) {
-            // a handful of primitives: every split into two parts, shared out over the lanes - exact where sixteen bins
+            // a handful of primitives: every split into two parts, shared out over the lanes - exact where bins
             // would be guessing.  Part `sub` (a mask over the range's places, the first place always in it) against the rest.
             const uint32_t full = (1u << k) - 1u;
             float best = PT_INF; uint32_t best_sub = 1u;

@@ -439,13 +439,28 @@ std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, 
     std::sort(by_range.begin(), by_range.end());
     std::vector<RangeContent> classes;
     std::vector<std::pair<std::pair<int32_t, int32_t>, int>> keyed;      // ((offset, count) of the object's class, object)
+    // a range whose length no other range has can share its content with nobody: it is not read at all when one object
+    // uses it (the usual scene of distinct meshes costs nothing here), and only for its smallest index when several do
+    std::vector<int32_t> lengths;
+    for (size_t i = 0; i < by_range.size(); i++)
+        if (i == 0 || by_range[i].first != by_range[i - 1].first) lengths.push_back(by_range[i].first.second);
+    std::sort(lengths.begin(), lengths.end());
     for (size_t i = 0; i < by_range.size();) {
-        const RangeContent rc = range_content(by_range[i].first.first, by_range[i].first.second, indices, vertices);
+        size_t j = i;
+        while (j < by_range.size() && by_range[j].first == by_range[i].first) j++;
+        const int32_t offset = by_range[i].first.first, count = by_range[i].first.second;
+        const bool length_shared = std::upper_bound(lengths.begin(), lengths.end(), count) - std::lower_bound(lengths.begin(), lengths.end(), count) > 1;
+        if (!length_shared && j - i < 2) { i = j; continue; }
+        RangeContent rc;
+        if (length_shared) rc = range_content(offset, count, indices, vertices);
+        else {
+            rc = RangeContent{offset, count, std::numeric_limits<int32_t>::max(), 0};
+            for (int32_t k = offset; k < offset + count; k++) rc.base = std::min(rc.base, indices[(size_t)k]);
+        }
         size_t cls = 0;
         while (cls < classes.size() && !same_content(classes[cls], rc, indices, vertices)) cls++;
         if (cls == classes.size()) classes.push_back(rc);
-        size_t j = i;
-        for (; j < by_range.size() && by_range[j].first == by_range[i].first; j++) {
+        for (j = i; j < by_range.size() && by_range[j].first == by_range[i].first; j++) {
             keyed.push_back({{classes[cls].offset, classes[cls].count}, by_range[j].second});
             obj_base[(size_t)by_range[j].second] = rc.base;
         }
@@ -534,7 +549,7 @@ struct DeviceArena {
 // The scene as pt_set_spheres / pt_set_meshes left it, every mesh object flattened (RayTracingShader.compute:236-240 applied
 // once instead of per ray), as a four-wide tree made on the device.  The host touches the objects and the spheres, never a
 // triangle.  Leaves the context exactly as the host build of a flat scene does, minus the two-child tree.
-int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt)
+int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt, std::chrono::steady_clock::time_point t_called)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const int nS = (int)ctx->spheres.size();
@@ -1002,12 +1017,13 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     ctx->n_prims = (int)nP; ctx->n_slots = n; ctx->n_top_records = n; ctx->n_spheres = nS;
     ctx->stack_need4 = stack_need;
     ctx->stats.bvh_nodes = n4; ctx->stats.bvh_prims = (int)nP; ctx->stats.bvh_depth = levels;
-    ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // from the moment the scene's rebuild began: the search for shared meshes before this function is part of the figure
+    ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_called).count();
     if (std::getenv("PTRACE_BUILD_TIMING")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "scene build on the device: %d primitives, %d references, %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; upload + bounds %.1f ms, "
+        std::fprintf(stderr, "scene build on the device: %d primitives, %d references, %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; before the build %.1f ms, upload + bounds %.1f ms, "
                              "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", (int)nP, n, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
-                     ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()));
+                     ms(t_called, t0), ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()));
     }
     ctx->scene_dirty = false;
     ctx->bvh2_stale = false;
@@ -1054,7 +1070,7 @@ int rebuild_scene(pt_context *ctx)
     }
     if (flat_is_quicker && ctx->bvh_width == 4 &&
         (ctx->tree_build == 1 || ctx->tree_build == 3 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
-        const int rc = build_scene_on_device(ctx, obj_first_tri, nt);
+        const int rc = build_scene_on_device(ctx, obj_first_tri, nt, t0);
         if (rc != kDeviceBuildFallback) return rc;
     }
 #endif
