@@ -300,16 +300,24 @@ __global__ __launch_bounds__(kBuildBlock) void sah_extra_kernel(const SahRange *
 }
 
 // One wave per listed node: its subtree, built in LDS.  order[] holds the node's primitives (as indices into the arrays
-// loaded below) so that every range still to be split is a stretch of it; the stack holds those ranges.
+// loaded below) so that every range still to be split is a stretch of it.  Ranges of more than kSahExhaustive primitives are
+// split by the whole wave, one after the other, with bins (the stack holds them); the ranges of kSahExhaustive or fewer that
+// fall out of that - seven of every eight nodes of the subtree lie in those - go on a list and are then finished by groups of
+// eight lanes, eight ranges side by side, each by trying every split into two parts.
 __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, const uint64_t *extra_offs, int extra_base, const float4 *p_lo, const float4 *p_hi, TwoChildTree tree)
 {
-    constexpr int S = kSahSmall;
+    constexpr int S = kSahSmall, E = kSahExhaustive;
+    static_assert(E == 8, "a group of eight lanes per listed range, one lane per place");
     __shared__ float blo[3][S], bhi[3][S];
     __shared__ int32_t ref[S];
     __shared__ uint8_t order[2][S];
     __shared__ uint32_t bins[kSahBinWords];
     __shared__ uint16_t stack_begin[S], stack_end[S];
     __shared__ int32_t stack_node[S];
+    __shared__ uint8_t tiny_begin[S / 2], tiny_count[S / 2];       // ranges of 2 .. E primitives, for the groups
+    __shared__ int32_t tiny_node[S / 2], tiny_first[S / 2];        // the range's node number; the first number for what lies below it
+    __shared__ uint8_t group_begin[8][E], group_count[8][E];       // a group's own stack while it finishes one listed range
+    __shared__ int32_t group_node[8][E];
     static_assert(S <= 256, "order[] holds bytes");
     const int lane = threadIdx.x;
     const SahRange r = small[blockIdx.x];
@@ -326,12 +334,18 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
         order[0][i] = (uint8_t)i;
     }
     int next_node = extra_base + (int)extra_offs[blockIdx.x];
-    int sp = 1;
-    if (lane == 0) { stack_begin[0] = 0; stack_end[0] = (uint16_t)count; stack_node[0] = r.node; }
+    int sp = 0, n_tiny = 0;
+    if (count <= E) {
+        if (lane == 0) { tiny_begin[0] = 0; tiny_count[0] = (uint8_t)count; tiny_node[0] = r.node; tiny_first[0] = next_node; }
+        n_tiny = 1;
+    } else {
+        if (lane == 0) { stack_begin[0] = 0; stack_end[0] = (uint16_t)count; stack_node[0] = r.node; }
+        sp = 1;
+    }
     __syncthreads();
     while (sp > 0) {
         sp--;
-        const int b = stack_begin[sp], e = stack_end[sp], node = stack_node[sp], k = e - b;
+        const int b = stack_begin[sp], e = stack_end[sp], node = stack_node[sp], k = e - b;      // k > E
         __syncthreads();                     // everyone has read the entry before it is overwritten
         float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};          // the range's box
         float cl[3] = {PT_INF, PT_INF, PT_INF}, ch[3] = {-PT_INF, -PT_INF, -PT_INF};        // and the bounds of its box centres
@@ -346,40 +360,8 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
         }
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) { l[ax] = wave_min(l[ax]); h[ax] = wave_max(h[ax]); cl[ax] = wave_min(cl[ax]); ch[ax] = wave_max(ch[ax]); }
-        int n_left = 1;
-        if (k > 2 && k <= kSahExhaustive) {
-            // a handful of primitives: every split into two parts, shared out over the lanes - exact where bins
-            // would be guessing.  Part `sub` (a mask over the range's places, the first place always in it) against the rest.
-            const uint32_t full = (1u << k) - 1u;
-            float best = PT_INF; uint32_t best_sub = 1u;
-            for (uint32_t c = (uint32_t)lane; c + 1u < (1u << (k - 1)); c += 64u) {
-                const uint32_t sub = (c << 1) | 1u;
-                SahBox lb, rb; sah_box_reset(lb); sah_box_reset(rb);
-                for (int j = 0; j < k; j++) {
-                    const int p = order[0][b + j];
-                    SahBox &t = ((sub >> j) & 1u) ? lb : rb;
-#pragma unroll
-                    for (int ax = 0; ax < 3; ax++) { t.l[ax] = fminf(t.l[ax], blo[ax][p]); t.h[ax] = fmaxf(t.h[ax], bhi[ax][p]); }
-                    t.n++;
-                }
-                const float cost = sah_box_cost(lb) + sah_box_cost(rb);
-                if (cost < best || (cost == best && sub < best_sub)) { best = cost; best_sub = sub; }
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const float oc = __shfl_xor(best, d, 64); const uint32_t os = __shfl_xor(best_sub, d, 64);
-                if (oc < best || (oc == best && os < best_sub)) { best = oc; best_sub = os; }
-            }
-            n_left = __popc(best_sub);
-            if (lane < k) {              // the members of best_sub to the front, order kept on both sides
-                const uint32_t below = (1u << lane) - 1u;
-                const int pos = ((best_sub >> lane) & 1u) ? __popc(best_sub & below) : n_left + __popc(~best_sub & full & below);
-                order[1][b + pos] = order[0][b + lane];
-            }
-            __syncthreads();
-            if (lane < k) order[0][b + lane] = order[1][b + lane];
-            __syncthreads();
-        } else if (k > 2) {
+        int n_left;
+        {
             for (int w = lane; w < kSahBinWords; w += 64) bins[w] = (w % 7) < 3 ? 0xffffffffu : 0u;
             __syncthreads();
             float scale[3];
@@ -463,8 +445,13 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
             int32_t link[2];
             const int part_begin[2] = {b, b + n_left}, part_end[2] = {b + n_left, e};
             for (int s = 0; s < 2; s++) {
-                if (part_end[s] - part_begin[s] == 1) link[s] = ref[order[0][part_begin[s]]];
-                else {
+                const int pk = part_end[s] - part_begin[s];
+                if (pk == 1) link[s] = ref[order[0][part_begin[s]]];
+                else if (pk <= E) {          // for the groups: its own number now, and the pk - 2 numbers below it set aside
+                    link[s] = next_node;
+                    tiny_begin[n_tiny] = (uint8_t)part_begin[s]; tiny_count[n_tiny] = (uint8_t)pk; tiny_node[n_tiny] = next_node; tiny_first[n_tiny] = next_node + 1;
+                    n_tiny++; next_node += pk - 1;
+                } else {
                     link[s] = next_node;
                     stack_begin[sp] = (uint16_t)part_begin[s]; stack_end[sp] = (uint16_t)part_end[s]; stack_node[sp] = next_node;
                     sp++; next_node++;
@@ -475,8 +462,83 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
             tree.hi[node] = make_float4(h[0], h[1], h[2], __int_as_float(k));
         }
         // the other lanes follow lane 0's bookkeeping
-        sp = __shfl(sp, 0, 64); next_node = __shfl(next_node, 0, 64);
+        sp = __shfl(sp, 0, 64); next_node = __shfl(next_node, 0, 64); n_tiny = __shfl(n_tiny, 0, 64);
         __syncthreads();
+    }
+    // ---- the listed ranges: group g takes ranges g, g + 8, ...; within a group every lane follows the same steps with the
+    // same numbers (what is pushed and which node numbers are given out depends on the split alone), lane 0 of the group writes.
+    // Nothing here is shared between groups, and a group's lanes run in step, so fences for the compiler are all it takes.
+    const int grp = lane >> 3, gl = lane & 7;
+    for (int t = grp; t < n_tiny; t += 8) {
+        int first = tiny_first[t], gsp = 1;
+        if (gl == 0) { group_begin[grp][0] = tiny_begin[t]; group_count[grp][0] = tiny_count[t]; group_node[grp][0] = tiny_node[t]; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        while (gsp > 0) {
+            gsp--;
+            const int b = group_begin[grp][gsp], k = group_count[grp][gsp], node = group_node[grp][gsp];
+            float pl[E][3], ph[E][3];
+            float l[3] = {PT_INF, PT_INF, PT_INF}, h[3] = {-PT_INF, -PT_INF, -PT_INF};
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int p = order[0][b + min(j, k - 1)];
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    pl[j][ax] = j < k ? blo[ax][p] : PT_INF; ph[j][ax] = j < k ? bhi[ax][p] : -PT_INF;
+                    l[ax] = fminf(l[ax], pl[j][ax]); h[ax] = fmaxf(h[ax], ph[j][ax]);
+                }
+            }
+            const int mine = order[0][b + min(gl, k - 1)];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (the stack entry and the places are read; they may be written now)
+            // every split into two parts, shared out over the group's lanes.  Part `sub` (a mask over the range's places, the
+            // first place always in it) against the rest; of equal costs the smaller mask.
+            const uint32_t full = (1u << k) - 1u;
+            float best = PT_INF; uint32_t best_sub = 1u;
+            for (uint32_t c = (uint32_t)gl; c + 1u < (1u << (k - 1)); c += 8u) {
+                const uint32_t sub = (c << 1) | 1u;
+                SahBox lb, rb; sah_box_reset(lb); sah_box_reset(rb);
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const bool in = (sub >> j) & 1u;       // (places from k on hold empty boxes and are in no mask: they change nothing but rb.n)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        lb.l[ax] = fminf(lb.l[ax], in ? pl[j][ax] : PT_INF); lb.h[ax] = fmaxf(lb.h[ax], in ? ph[j][ax] : -PT_INF);
+                        rb.l[ax] = fminf(rb.l[ax], in ? PT_INF : pl[j][ax]); rb.h[ax] = fmaxf(rb.h[ax], in ? -PT_INF : ph[j][ax]);
+                    }
+                }
+                lb.n = (uint32_t)__popc(sub); rb.n = (uint32_t)k - lb.n;
+                const float cost = sah_box_cost(lb) + sah_box_cost(rb);
+                if (cost < best || (cost == best && sub < best_sub)) { best = cost; best_sub = sub; }
+            }
+#pragma unroll
+            for (int d = 4; d >= 1; d >>= 1) {
+                const float oc = __shfl_xor(best, d, 8); const uint32_t os = __shfl_xor(best_sub, d, 8);
+                if (oc < best || (oc == best && os < best_sub)) { best = oc; best_sub = os; }
+            }
+            const int n_left = __popc(best_sub);
+            if (gl < k) {                // the members of best_sub to the front, order kept on both sides
+                const uint32_t below = (1u << gl) - 1u;
+                const int pos = ((best_sub >> gl) & 1u) ? __popc(best_sub & below) : n_left + __popc(~best_sub & full & below);
+                order[0][b + pos] = (uint8_t)mine;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            int32_t link[2];
+            const int part_begin[2] = {b, b + n_left}, part_count[2] = {n_left, k - n_left};
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (part_count[s] == 1) link[s] = ref[order[0][part_begin[s]]];
+                else {
+                    link[s] = first;
+                    if (gl == 0) { group_begin[grp][gsp] = (uint8_t)part_begin[s]; group_count[grp][gsp] = (uint8_t)part_count[s]; group_node[grp][gsp] = first; }
+                    gsp++; first++;
+                }
+            }
+            if (gl == 0) {
+                tree.child[node] = make_int2(link[0], link[1]);
+                tree.lo[node] = make_float4(l[0], l[1], l[2], __int_as_float(node));
+                tree.hi[node] = make_float4(h[0], h[1], h[2], __int_as_float(k));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
     }
 }
 
