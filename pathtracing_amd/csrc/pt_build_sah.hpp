@@ -8,7 +8,8 @@
 //
 //   upper levels, one pass per level over all primitives (they lie in Morton order, and a stable partition keeps every
 //   node's primitives one contiguous, still Morton-ordered range):
-//     sah_centres_kernel    the bounds of the box centres of every node's primitives: the range its bins are laid over
+//     sah_centres_kernel    the bounds of the box centres of the root's primitives: the range its bins are laid over (for the
+//                           levels below, sah_side_kernel collects them while it sorts the primitives into children)
 //     sah_bin_kernel        every primitive of a node with more than kSahSmall adds its box to one of 32 bins per axis of
 //                           its node (by its centre's place among the node's centres); a wave collects in LDS bins of its
 //                           own what goes to the node it is in, and sends them on when it comes to the next node
@@ -253,24 +254,70 @@ __global__ __launch_bounds__(kBuildBlock) void sah_next_kernel(const SahRange *c
     else { small[small_base + (int)(o >> 32)] = cand[c]; slot[c] = -1; }
 }
 
+// left[i]: whether the primitive at place i goes to its node's left child.  On the way, the bounds of the box centres of
+// every child that forms the next level (slot[c] >= 0: its index there) are collected in cb_next, which the caller has filled
+// with sah_fill_centres_kernel - what sah_centres_kernel would find after the partition, without another pass.  A wave takes
+// kWaveChunk consecutive places and sends its share of a node's two children when it comes to the next node.
 __global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, const uint32_t *cb, const int4 *split,
-                                                               uint32_t *left)
+                                                               const int32_t *slot, uint32_t *left, uint32_t *cb_next)
 {
-    const int i = blockIdx.x * kBuildBlock + threadIdx.x;
-    if (i >= n) return;
-    const int a = seg[i];
-    uint32_t l = 0;
-    if (a >= 0) {
+    const int lane = threadIdx.x & 63;
+    const size_t chunk = ((size_t)blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6)) * kWaveChunk;
+    if (chunk >= (size_t)n) return;
+    float cl[2][3], ch[2][3];                // this lane's share of the two children of node `held`
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { cl[s][k] = PT_INF; ch[s][k] = -PT_INF; }
+    int held = -1;                           // the same in every lane
+    const auto flush = [&]() {
+        if (held < 0) return;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int to = slot[2 * held + s];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float a = wave_min(cl[s][k]), b = wave_max(ch[s][k]);
+                if (lane == 0 && to >= 0 && a <= b) { atomicMin(cb_next + (size_t)to * 6 + k, ordered_bits(a)); atomicMax(cb_next + (size_t)to * 6 + 3 + k, ordered_bits(b)); }
+                cl[s][k] = PT_INF; ch[s][k] = -PT_INF;
+            }
+        }
+    };
+    for (int step = 0; step < kWaveChunk / 64; step++) {
+        const size_t first = chunk + (size_t)step * 64;
+        if (first >= (size_t)n) break;
+        const size_t i = first + (size_t)lane;
+        const bool valid = i < (size_t)n;
+        const int a = valid ? seg[i] : -1;
+        const int lead = __builtin_amdgcn_readfirstlane(a);
+        const bool one_node = __all(a == lead);
+        if (!one_node || a != held) { flush(); held = one_node ? a : -1; }
+        if (a < 0) { if (valid) left[i] = 0; continue; }
         const int4 sp = split[a];
-        if (sp.x < 0) l = i - act[a].begin < sp.z;
+        const float4 pl = p_lo[i], ph = p_hi[i];
+        uint32_t l;
+        if (sp.x < 0) l = (int)i - act[a].begin < sp.z;
         else {
             const float rl = ordered_to_float(cb[(size_t)a * 6 + sp.x]), rh = ordered_to_float(cb[(size_t)a * 6 + 3 + sp.x]);
-            const float4 pl = p_lo[i], ph = p_hi[i];
             const float lo = sp.x == 0 ? pl.x : sp.x == 1 ? pl.y : pl.z, hi = sp.x == 0 ? ph.x : sp.x == 1 ? ph.y : ph.z;
             l = sah_bin(lo, hi, rl, sah_scale(rl, rh)) <= sp.y;
         }
+        left[i] = l;
+        const float c[3] = {0.5f * pl.x + 0.5f * ph.x, 0.5f * pl.y + 0.5f * ph.y, 0.5f * pl.z + 0.5f * ph.z};
+        if (one_node) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                cl[0][k] = fminf(cl[0][k], l ? c[k] : PT_INF); ch[0][k] = fmaxf(ch[0][k], l ? c[k] : -PT_INF);
+                cl[1][k] = fminf(cl[1][k], l ? PT_INF : c[k]); ch[1][k] = fmaxf(ch[1][k], l ? -PT_INF : c[k]);
+            }
+        } else {
+            const int to = slot[2 * a + (l ? 0 : 1)];
+            if (to >= 0)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { atomicMin(cb_next + (size_t)to * 6 + k, ordered_bits(c[k])); atomicMax(cb_next + (size_t)to * 6 + 3 + k, ordered_bits(c[k])); }
+        }
     }
-    left[i] = l;
+    flush();
 }
 
 // rank = exclusive prefix sums of left.  Within each node's range: the left primitives first, the right ones after, both in

@@ -591,7 +591,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         int32_t *items[2], *stacked[2]; int4 *kids;
         uint4 *nodes4; uint32_t *slot_prim, *slot_prim_dfs; int32_t *stack_need;
         int2 *below, *place;
-        SahRange *act[2], *cand, *small; int32_t *slot; int4 *split; uint32_t *bins, *centres;
+        SahRange *act[2], *cand, *small; int32_t *slot; int4 *split; uint32_t *bins, *centres[2];
         char *temp;
     } d{};
     const size_t n_bounds = 6 * (nO + 1);
@@ -733,7 +733,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         a.take(d.kids, nR); a.take(d.nodes4, nR * 4); a.take(d.slot_prim, nR + 1); a.take(d.slot_prim_dfs, nR + 1); a.take(d.stack_need, 64);
         a.take(d.below, nR); a.take(d.place, nR);
         a.take(d.act[0], sah_nodes); a.take(d.act[1], sah_nodes); a.take(d.cand, 2 * sah_nodes); a.take(d.small, nR); a.take(d.slot, 2 * sah_nodes); a.take(d.split, sah_nodes);
-        a.take(d.bins, sah_nodes * kSahBinWords); a.take(d.centres, sah_nodes * 6);
+        a.take(d.bins, sah_nodes * kSahBinWords); a.take(d.centres[0], sah_nodes * 6); a.take(d.centres[1], sah_nodes * 6);
         a.take(d.temp, temp_bytes);
     };
     {
@@ -808,16 +808,22 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         while (n_act > 0) {
             if (level >= kDeviceBuildMaxLevels || (size_t)node_base + 2 * (size_t)n_act + nR > tree_cap) return kDeviceBuildFallback;
             const SahRange *act = d.act[level & 1];
-            hipLaunchKernelGGL(sah_fill_centres_kernel, grid((size_t)n_act * 6), dim3(kBuildBlock), 0, st, d.centres, n_act * 6);
-            hipLaunchKernelGGL(sah_centres_kernel, dim3((unsigned)wave_chunk_blocks(nR)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres);
+            uint32_t *centres = d.centres[level & 1], *centres_next = d.centres[(level + 1) & 1];
+            if (level == 0) {                 // below the root, the level above has collected them (sah_side_kernel)
+                hipLaunchKernelGGL(sah_fill_centres_kernel, grid((size_t)n_act * 6), dim3(kBuildBlock), 0, st, centres, n_act * 6);
+                hipLaunchKernelGGL(sah_centres_kernel, dim3((unsigned)wave_chunk_blocks(nR)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, centres);
+            }
             hipLaunchKernelGGL(sah_fill_kernel, grid((size_t)n_act * kSahBinWords), dim3(kBuildBlock), 0, st, d.bins, (size_t)n_act * kSahBinWords);
-            hipLaunchKernelGGL(sah_bin_kernel, dim3((unsigned)((nR + (size_t)kBinChunk * (kBuildBlock / 64) - 1) / ((size_t)kBinChunk * (kBuildBlock / 64)))), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, d.centres, d.bins);
+            hipLaunchKernelGGL(sah_bin_kernel, dim3((unsigned)((nR + (size_t)kBinChunk * (kBuildBlock / 64) - 1) / ((size_t)kBinChunk * (kBuildBlock / 64)))), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, centres, d.bins);
             hipLaunchKernelGGL(sah_split_kernel, grid((size_t)n_act), dim3(kBuildBlock), 0, st, act, n_act, d.bins, node_base, tree, d.split, d.cand, d.flags);
             size_t bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)(2 * n_act), rocprim::plus<uint64_t>(), st));
             hipLaunchKernelGGL(sah_next_kernel, grid((size_t)(2 * n_act)), dim3(kBuildBlock), 0, st, d.cand, 2 * n_act, d.flags, d.offs, d.act[(level + 1) & 1], d.small, n_small, d.slot,
                                d.totals);
-            hipLaunchKernelGGL(sah_side_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.centres, d.split, left);
+            const int next_words = 6 * (int)std::min<size_t>(2 * (size_t)n_act, sah_nodes);      // (the next level has at most sah_nodes - 2 nodes)
+            hipLaunchKernelGGL(sah_fill_centres_kernel, grid((size_t)next_words), dim3(kBuildBlock), 0, st, centres_next, next_words);
+            hipLaunchKernelGGL(sah_side_kernel, dim3((unsigned)wave_chunk_blocks(nR)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, centres, d.split, d.slot, left,
+                               centres_next);
             bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, left, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(sah_partition_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left, rank, d.slot, d.cl_lo[cur ^ 1],
