@@ -130,8 +130,8 @@ __device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as
 // Every wave takes kBinChunk consecutive places, 64 at a time, and collects in LDS bins of its own what goes to its `home`
 // node - the node all 64 places of a step belong to; when that changes, the bins are sent to the old home's global bins and
 // start again.  Nodes are contiguous and hold more than kSahSmall primitives, so nearly everything goes through LDS at every
-// level: a few dozen global atomics per node and wave instead of 21 per primitive.  Lanes of a step that straddles two nodes
-// send what is not home's to the global bins directly.  (Only the wave itself touches its bins: no block barrier.)
+// level: a few dozen global atomics per node and wave instead of 21 per primitive.  A step that straddles nodes is taken node
+// by node.  (Only the wave itself touches its bins: no block barrier.)
 constexpr int kBinChunk = 64 * 8;
 __global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const uint32_t *cb, uint32_t *bins)
 {
@@ -159,23 +159,31 @@ __global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo
         if (at >= (size_t)n) break;
         const size_t i = at + lane;
         const int a = i < (size_t)n ? seg[i] : -1;
-        const int lead = __builtin_amdgcn_readfirstlane(a);
-        if (lead >= 0 && lead != home && __all(a == lead)) { flush(); home = lead; }
-        if (a < 0) continue;
-        const uint32_t *r = cb + (size_t)a * 6;
-        const float4 pl = p_lo[i], ph = p_hi[i];
-        const float l[3] = {pl.x, pl.y, pl.z}, h[3] = {ph.x, ph.y, ph.z};
-        uint32_t ol[3], oh[3];
+        float l[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+        uint32_t ol[3] = {0, 0, 0}, oh[3] = {0, 0, 0};
+        if (a >= 0) {
+            const float4 pl = p_lo[i], ph = p_hi[i];
+            l[0] = pl.x; l[1] = pl.y; l[2] = pl.z; h[0] = ph.x; h[1] = ph.y; h[2] = ph.z;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { ol[k] = ordered_bits(l[k]); oh[k] = ordered_bits(h[k]); }
-        uint32_t *dst = a == home ? local : bins + (size_t)a * kSahBinWords;
+            for (int k = 0; k < 3; k++) { ol[k] = ordered_bits(l[k]); oh[k] = ordered_bits(h[k]); }
+        }
+        // the step's places node by node (a node's places are consecutive: one node nearly always, a few where small nodes meet)
+        unsigned long long todo = __ballot(a >= 0);
+        while (todo) {
+            const int node = __shfl(a, __ffsll((long long)todo) - 1, 64);
+            if (node != home) { flush(); home = node; }
+            if (a == node) {
+                const uint32_t *r = cb + (size_t)a * 6;
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) {
-            const float rl = ordered_to_float(r[ax]), rh = ordered_to_float(r[3 + ax]);
-            uint32_t *w = dst + (ax * kSahBins + sah_bin(l[ax], h[ax], rl, sah_scale(rl, rh))) * 7;
+                for (int ax = 0; ax < 3; ax++) {
+                    const float rl = ordered_to_float(r[ax]), rh = ordered_to_float(r[3 + ax]);
+                    uint32_t *w = local + (ax * kSahBins + sah_bin(l[ax], h[ax], rl, sah_scale(rl, rh))) * 7;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { atomicMin(w + k, ol[k]); atomicMax(w + 3 + k, oh[k]); }
-            atomicAdd(w + 6, 1u);
+                    for (int k = 0; k < 3; k++) { atomicMin(w + k, ol[k]); atomicMax(w + 3 + k, oh[k]); }
+                    atomicAdd(w + 6, 1u);
+                }
+            }
+            todo &= ~__ballot(a == node);
         }
     }
     flush();
@@ -275,6 +283,11 @@ __global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_l
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const int to = slot[2 * held + s];
+            if (to < 0) {                    // a child that leaves the levels needs no bins
+#pragma unroll
+                for (int k = 0; k < 3; k++) { cl[s][k] = PT_INF; ch[s][k] = -PT_INF; }
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float a = wave_min(cl[s][k]), b = wave_max(ch[s][k]);
@@ -289,32 +302,33 @@ __global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_l
         const size_t i = first + (size_t)lane;
         const bool valid = i < (size_t)n;
         const int a = valid ? seg[i] : -1;
-        const int lead = __builtin_amdgcn_readfirstlane(a);
-        const bool one_node = __all(a == lead);
-        if (!one_node || a != held) { flush(); held = one_node ? a : -1; }
-        if (a < 0) { if (valid) left[i] = 0; continue; }
-        const int4 sp = split[a];
-        const float4 pl = p_lo[i], ph = p_hi[i];
-        uint32_t l;
-        if (sp.x < 0) l = (int)i - act[a].begin < sp.z;
-        else {
-            const float rl = ordered_to_float(cb[(size_t)a * 6 + sp.x]), rh = ordered_to_float(cb[(size_t)a * 6 + 3 + sp.x]);
-            const float lo = sp.x == 0 ? pl.x : sp.x == 1 ? pl.y : pl.z, hi = sp.x == 0 ? ph.x : sp.x == 1 ? ph.y : ph.z;
-            l = sah_bin(lo, hi, rl, sah_scale(rl, rh)) <= sp.y;
-        }
-        left[i] = l;
-        const float c[3] = {0.5f * pl.x + 0.5f * ph.x, 0.5f * pl.y + 0.5f * ph.y, 0.5f * pl.z + 0.5f * ph.z};
-        if (one_node) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                cl[0][k] = fminf(cl[0][k], l ? c[k] : PT_INF); ch[0][k] = fmaxf(ch[0][k], l ? c[k] : -PT_INF);
-                cl[1][k] = fminf(cl[1][k], l ? PT_INF : c[k]); ch[1][k] = fmaxf(ch[1][k], l ? -PT_INF : c[k]);
+        uint32_t l = 0;
+        float c[3] = {0, 0, 0};
+        if (a >= 0) {
+            const int4 sp = split[a];
+            const float4 pl = p_lo[i], ph = p_hi[i];
+            if (sp.x < 0) l = (int)i - act[a].begin < sp.z;
+            else {
+                const float rl = ordered_to_float(cb[(size_t)a * 6 + sp.x]), rh = ordered_to_float(cb[(size_t)a * 6 + 3 + sp.x]);
+                const float lo = sp.x == 0 ? pl.x : sp.x == 1 ? pl.y : pl.z, hi = sp.x == 0 ? ph.x : sp.x == 1 ? ph.y : ph.z;
+                l = sah_bin(lo, hi, rl, sah_scale(rl, rh)) <= sp.y;
             }
-        } else {
-            const int to = slot[2 * a + (l ? 0 : 1)];
-            if (to >= 0)
+            c[0] = 0.5f * pl.x + 0.5f * ph.x; c[1] = 0.5f * pl.y + 0.5f * ph.y; c[2] = 0.5f * pl.z + 0.5f * ph.z;
+        }
+        if (valid) left[i] = l;
+        // the step's places node by node (one node nearly always)
+        unsigned long long todo = __ballot(a >= 0);
+        while (todo) {
+            const int node = __shfl(a, __ffsll((long long)todo) - 1, 64);
+            if (node != held) { flush(); held = node; }
+            if (a == node) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) { atomicMin(cb_next + (size_t)to * 6 + k, ordered_bits(c[k])); atomicMax(cb_next + (size_t)to * 6 + 3 + k, ordered_bits(c[k])); }
+                for (int k = 0; k < 3; k++) {
+                    cl[0][k] = fminf(cl[0][k], l ? c[k] : PT_INF); ch[0][k] = fmaxf(ch[0][k], l ? c[k] : -PT_INF);
+                    cl[1][k] = fminf(cl[1][k], l ? PT_INF : c[k]); ch[1][k] = fmaxf(ch[1][k], l ? -PT_INF : c[k]);
+                }
+            }
+            todo &= ~__ballot(a == node);
         }
     }
     flush();
