@@ -132,6 +132,26 @@ __device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as
 // start again.  Nodes are contiguous and hold more than kSahSmall primitives, so nearly everything goes through LDS at every
 // level: a few dozen global atomics per node and wave instead of 21 per primitive.  A step that straddles nodes is taken node
 // by node.  (Only the wave itself touches its bins: no block barrier.)
+// The smallest / largest value among the 16 lanes of a row (lanes 16 r .. 16 r + 15), in all of them: four exchanges through the
+// data-parallel-primitive lane selects (neighbour, other pair of the quad, mirror within 8, mirror within 16).  Every lane
+// of the row must be active.
+__device__ __forceinline__ uint32_t row_umin(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ uint32_t row_umax(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+
 constexpr int kBinChunk = 64 * 8;
 __global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const uint32_t *cb, uint32_t *bins)
 {
@@ -172,12 +192,28 @@ __global__ __launch_bounds__(kBuildBlock) void sah_bin_kernel(const float4 *p_lo
         while (todo) {
             const int node = __shfl(a, __ffsll((long long)todo) - 1, 64);
             if (node != home) { flush(); home = node; }
-            if (a == node) {
-                const uint32_t *r = cb + (size_t)a * 6;
+            // Neighbours in Morton order mostly fall into one bin, and 64 atomics on one LDS word take their turns: where the 16
+            // lanes of a row all belong to the node and agree on an axis' bin, the row is reduced in registers first and one
+            // lane sends it.
+            const bool mine = a == node;
+            const uint32_t *r = cb + (size_t)node * 6;
 #pragma unroll
-                for (int ax = 0; ax < 3; ax++) {
-                    const float rl = ordered_to_float(r[ax]), rh = ordered_to_float(r[3 + ax]);
-                    uint32_t *w = local + (ax * kSahBins + sah_bin(l[ax], h[ax], rl, sah_scale(rl, rh))) * 7;
+            for (int ax = 0; ax < 3; ax++) {
+                const float rl = ordered_to_float(r[ax]), rh = ordered_to_float(r[3 + ax]);
+                const uint32_t bin = mine ? (uint32_t)sah_bin(l[ax], h[ax], rl, sah_scale(rl, rh)) : 0xffffffffu;
+                const uint32_t bmax = row_umax(bin);
+                if (bmax != 0xffffffffu && row_umin(bin) == bmax) {
+                    uint32_t rlo[3], rhi[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { rlo[k] = row_umin(ol[k]); rhi[k] = row_umax(oh[k]); }
+                    if ((lane & 15) == 0) {
+                        uint32_t *w = local + (ax * kSahBins + (int)bin) * 7;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { atomicMin(w + k, rlo[k]); atomicMax(w + 3 + k, rhi[k]); }
+                        atomicAdd(w + 6, 16u);
+                    }
+                } else if (mine) {
+                    uint32_t *w = local + (ax * kSahBins + (int)bin) * 7;
 #pragma unroll
                     for (int k = 0; k < 3; k++) { atomicMin(w + k, ol[k]); atomicMax(w + 3 + k, oh[k]); }
                     atomicAdd(w + 6, 1u);
