@@ -185,7 +185,8 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                2 (default): the device for scenes of 16 384 primitives or more, the host below.  Large triangles
  *                are cut into references ("split_percent") in a device build as in a host build.
  *                3: the device, with the two-child tree made by locally-ordered clustering from
- *                the leaves up - half the build time again (21 ms for ten million), a fifth more node visits per ray.
+ *                the leaves up - a third less build time on the largest scenes (21 ms for ten million), a fifth more
+ *                node visits per ray.
  *                Four-child tree only; a tree too deep for a lane's traversal stack is handed to the host builder.
  *   "rebuild_percent"  30 (default): pt_update_transforms refits, which keeps the topology of the last build - after
  *                large motion the boxes overlap and rays visit more nodes.  The summed node area of a refitted
