@@ -239,33 +239,77 @@ __device__ __forceinline__ float sah_box_cost(const SahBox &b)
     return (ex * ey + ey * ez + ez * ex) * (float)b.n;
 }
 
+// The cheapest of the 93 splits "bins 0 .. s of an axis against bins s + 1 .. 31", found by a whole wave: two rounds of 32-lane
+// halves, a half per axis; every lane takes a bin, prefix and suffix unions run over the half (five shuffle steps each), and
+// the lane of bin s prices its split.  Candidate c = axis * 31 + s; of equal costs the smallest c (the order a loop over the
+// axes and bins would meet them in).  The result is the same in every lane; cost is PT_INF when no split has primitives on
+// both sides and a finite price.
+struct SahPick { float cost; int cand; SahBox left, right; };
+__device__ __forceinline__ SahPick sah_pick_split(const uint32_t *bins, int lane)
+{
+    static_assert(kSahBins == 32, "one bin per lane of a half-wave");
+    SahPick pick;
+    pick.cost = PT_INF; pick.cand = 3 * (kSahBins - 1);
+    sah_box_reset(pick.left); sah_box_reset(pick.right);
+    for (int round = 0; round < 2; round++) {
+        const int ax = 2 * round + (lane >> 5), bin = lane & 31;
+        SahBox pre; sah_box_reset(pre);
+        if (ax < 3) sah_box_add(pre, bins + (ax * kSahBins + bin) * 7);
+        SahBox suf = pre;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            SahBox up, down;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                up.l[q] = __shfl_up(pre.l[q], d, 32); up.h[q] = __shfl_up(pre.h[q], d, 32);
+                down.l[q] = __shfl_down(suf.l[q], d, 32); down.h[q] = __shfl_down(suf.h[q], d, 32);
+            }
+            up.n = __shfl_up(pre.n, d, 32); down.n = __shfl_down(suf.n, d, 32);
+            if (bin >= d) { for (int q = 0; q < 3; q++) { pre.l[q] = fminf(pre.l[q], up.l[q]); pre.h[q] = fmaxf(pre.h[q], up.h[q]); } pre.n += up.n; }
+            if (bin + d < 32) { for (int q = 0; q < 3; q++) { suf.l[q] = fminf(suf.l[q], down.l[q]); suf.h[q] = fmaxf(suf.h[q], down.h[q]); } suf.n += down.n; }
+        }
+        SahBox right;            // bins bin + 1 .. 31: the neighbour's suffix
+#pragma unroll
+        for (int q = 0; q < 3; q++) { right.l[q] = __shfl_down(suf.l[q], 1, 32); right.h[q] = __shfl_down(suf.h[q], 1, 32); }
+        right.n = __shfl_down(suf.n, 1, 32);
+        if (ax < 3 && bin < kSahBins - 1 && pre.n && right.n) {
+            const float cost = sah_box_cost(pre) + sah_box_cost(right);
+            if (cost < pick.cost) { pick.cost = cost; pick.cand = ax * (kSahBins - 1) + bin; pick.left = pre; pick.right = right; }
+        }
+    }
+    float best = pick.cost; int best_cand = pick.cand;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float oc = __shfl_xor(best, d, 64); const int ocand = __shfl_xor(best_cand, d, 64);
+        if (oc < best || (oc == best && ocand < best_cand)) { best = oc; best_cand = ocand; }
+    }
+    // the boxes of the winning split, from the lane that priced it
+    const int winner = ((best_cand / (kSahBins - 1)) & 1) * 32 + best_cand % (kSahBins - 1);
+    pick.cost = best; pick.cand = best_cand;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        pick.left.l[q] = __shfl(pick.left.l[q], winner, 64); pick.left.h[q] = __shfl(pick.left.h[q], winner, 64);
+        pick.right.l[q] = __shfl(pick.right.l[q], winner, 64); pick.right.h[q] = __shfl(pick.right.h[q], winner, 64);
+    }
+    pick.left.n = __shfl(pick.left.n, winner, 64); pick.right.n = __shfl(pick.right.n, winner, 64);
+    return pick;
+}
+
 // split[a] = (axis or -1, last bin of the left part, primitives on the left, 0).  Candidates 2 a and 2 a + 1 are the
-// children; flags says which of them form the next level (low word) and which go on the list (high word).
+// children; flags says which of them form the next level (low word) and which go on the list (high word).  One wave per node.
 __global__ __launch_bounds__(kBuildBlock) void sah_split_kernel(const SahRange *act, int n_act, const uint32_t *bins, int node_base, TwoChildTree tree, int4 *split,
                                                                 SahRange *cand, uint64_t *flags)
 {
-    const int a = blockIdx.x * kBuildBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6);
     if (a >= n_act) return;
     const SahRange r = act[a];
-    const uint32_t *nb = bins + (size_t)a * kSahBinWords;
-    int best_axis = -1, best_bin = 0; float best_cost = PT_INF;
-    for (int ax = 0; ax < 3; ax++) {
-        float right_cost[kSahBins];          // right_cost[s]: bins s + 1 .. 31
-        SahBox acc; sah_box_reset(acc);
-        for (int b = kSahBins - 1; b >= 1; b--) { sah_box_add(acc, nb + (ax * kSahBins + b) * 7); right_cost[b - 1] = acc.n ? sah_box_cost(acc) : PT_INF; }
-        sah_box_reset(acc);
-        for (int s = 0; s < kSahBins - 1; s++) {
-            sah_box_add(acc, nb + (ax * kSahBins + s) * 7);
-            if (!acc.n || !(right_cost[s] < PT_INF)) continue;
-            const float c = sah_box_cost(acc) + right_cost[s];
-            if (c < best_cost) { best_cost = c; best_axis = ax; best_bin = s; }
-        }
-    }
-    SahBox left, right;
-    if (best_axis >= 0) {
-        sah_box_reset(left); sah_box_reset(right);
-        for (int b = 0; b < kSahBins; b++) sah_box_add(b <= best_bin ? left : right, nb + (best_axis * kSahBins + b) * 7);
-    } else {
+    const SahPick pick = sah_pick_split(bins + (size_t)a * kSahBinWords, lane);
+    if (lane != 0) return;
+    int best_axis = -1, best_bin = 0;
+    SahBox left = pick.left, right = pick.right;
+    if (pick.cost < PT_INF) { best_axis = pick.cand / (kSahBins - 1); best_bin = pick.cand % (kSahBins - 1); }
+    else {
         // every centre in one bin on every axis: halve the range as it lies; the children's boxes are the parent's (they
         // hold what is in them, which is all a box has to do)
         for (int k = 0; k < 3; k++) { left.l[k] = right.l[k] = r.lo[k]; left.h[k] = right.h[k] = r.hi[k]; }
@@ -301,12 +345,13 @@ __global__ __launch_bounds__(kBuildBlock) void sah_next_kernel(const SahRange *c
 // left[i]: whether the primitive at place i goes to its node's left child.  On the way, the bounds of the box centres of
 // every child that forms the next level (slot[c] >= 0: its index there) are collected in cb_next, which the caller has filled
 // with sah_fill_centres_kernel - what sah_centres_kernel would find after the partition, without another pass.  A wave takes
-// kWaveChunk consecutive places and sends its share of a node's two children when it comes to the next node.
+// `places` consecutive places (a multiple of 64: many while the level has few nodes and every wave's atomics meet on the same
+// words, few once they spread) and sends its share of a node's two children when it comes to the next node.
 __global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_lo, const float4 *p_hi, const int32_t *seg, int n, const SahRange *act, const uint32_t *cb, const int4 *split,
-                                                               const int32_t *slot, uint32_t *left, uint32_t *cb_next)
+                                                               const int32_t *slot, uint32_t *left, uint32_t *cb_next, int places)
 {
     const int lane = threadIdx.x & 63;
-    const size_t chunk = ((size_t)blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6)) * kWaveChunk;
+    const size_t chunk = ((size_t)blockIdx.x * (kBuildBlock / 64) + (threadIdx.x >> 6)) * (size_t)places;
     if (chunk >= (size_t)n) return;
     float cl[2][3], ch[2][3];                // this lane's share of the two children of node `held`
 #pragma unroll
@@ -332,7 +377,7 @@ __global__ __launch_bounds__(kBuildBlock) void sah_side_kernel(const float4 *p_l
             }
         }
     };
-    for (int step = 0; step < kWaveChunk / 64; step++) {
+    for (int step = 0; step < places / 64; step++) {
         const size_t first = chunk + (size_t)step * 64;
         if (first >= (size_t)n) break;
         const size_t i = first + (size_t)lane;
@@ -478,43 +523,8 @@ __global__ __launch_bounds__(64) void sah_small_kernel(const SahRange *small, co
                 }
             }
             __syncthreads();
-            // candidate c = axis * (kSahBins - 1) + s: the split after bin s of that axis.  Two rounds of 32-lane halves, a
-            // half per axis: every lane takes a bin, prefix and suffix unions run over the half (five shuffle steps each), and
-            // the lane of bin s prices "bins 0..s against s+1..31".
-            static_assert(kSahBins == 32, "one bin per lane of a half-wave");
-            float best = PT_INF; int best_cand = 3 * (kSahBins - 1); uint32_t my_left = 0;
-            for (int round = 0; round < 2; round++) {
-                const int ax = 2 * round + (lane >> 5), bin = lane & 31;
-                SahBox pre; sah_box_reset(pre);
-                if (ax < 3) sah_box_add(pre, bins + (ax * kSahBins + bin) * 7);
-                SahBox suf = pre;
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) {
-                    SahBox up, down;
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        up.l[q] = __shfl_up(pre.l[q], d, 32); up.h[q] = __shfl_up(pre.h[q], d, 32);
-                        down.l[q] = __shfl_down(suf.l[q], d, 32); down.h[q] = __shfl_down(suf.h[q], d, 32);
-                    }
-                    up.n = __shfl_up(pre.n, d, 32); down.n = __shfl_down(suf.n, d, 32);
-                    if (bin >= d) { for (int q = 0; q < 3; q++) { pre.l[q] = fminf(pre.l[q], up.l[q]); pre.h[q] = fmaxf(pre.h[q], up.h[q]); } pre.n += up.n; }
-                    if (bin + d < 32) { for (int q = 0; q < 3; q++) { suf.l[q] = fminf(suf.l[q], down.l[q]); suf.h[q] = fmaxf(suf.h[q], down.h[q]); } suf.n += down.n; }
-                }
-                SahBox right;            // bins bin + 1 .. 31: the neighbour's suffix
-#pragma unroll
-                for (int q = 0; q < 3; q++) { right.l[q] = __shfl_down(suf.l[q], 1, 32); right.h[q] = __shfl_down(suf.h[q], 1, 32); }
-                right.n = __shfl_down(suf.n, 1, 32);
-                if (ax < 3 && bin < kSahBins - 1 && pre.n && right.n) {
-                    const float cost = sah_box_cost(pre) + sah_box_cost(right);
-                    const int c = ax * (kSahBins - 1) + bin;
-                    if (cost < best) { best = cost; best_cand = c; my_left = pre.n; }
-                }
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const float oc = __shfl_xor(best, d, 64); const int ocand = __shfl_xor(best_cand, d, 64); const uint32_t oleft = __shfl_xor(my_left, d, 64);
-                if (oc < best || (oc == best && ocand < best_cand)) { best = oc; best_cand = ocand; my_left = oleft; }
-            }
+            const SahPick pick = sah_pick_split(bins, lane);
+            const float best = pick.cost; const int best_cand = pick.cand; const uint32_t my_left = pick.left.n;
             if (best < PT_INF) {
                 n_left = (int)my_left;
                 const int ax = best_cand / (kSahBins - 1), s = best_cand % (kSahBins - 1);

@@ -815,15 +815,17 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
             }
             hipLaunchKernelGGL(sah_fill_kernel, grid((size_t)n_act * kSahBinWords), dim3(kBuildBlock), 0, st, d.bins, (size_t)n_act * kSahBinWords);
             hipLaunchKernelGGL(sah_bin_kernel, dim3((unsigned)((nR + (size_t)kBinChunk * (kBuildBlock / 64) - 1) / ((size_t)kBinChunk * (kBuildBlock / 64)))), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, centres, d.bins);
-            hipLaunchKernelGGL(sah_split_kernel, grid((size_t)n_act), dim3(kBuildBlock), 0, st, act, n_act, d.bins, node_base, tree, d.split, d.cand, d.flags);
+            hipLaunchKernelGGL(sah_split_kernel, grid((size_t)n_act * 64), dim3(kBuildBlock), 0, st, act, n_act, d.bins, node_base, tree, d.split, d.cand, d.flags);      // a wave per node
             size_t bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, d.flags, d.offs, (uint64_t)0, (size_t)(2 * n_act), rocprim::plus<uint64_t>(), st));
             hipLaunchKernelGGL(sah_next_kernel, grid((size_t)(2 * n_act)), dim3(kBuildBlock), 0, st, d.cand, 2 * n_act, d.flags, d.offs, d.act[(level + 1) & 1], d.small, n_small, d.slot,
                                d.totals);
             const int next_words = 6 * (int)std::min<size_t>(2 * (size_t)n_act, sah_nodes);      // (the next level has at most sah_nodes - 2 nodes)
             hipLaunchKernelGGL(sah_fill_centres_kernel, grid((size_t)next_words), dim3(kBuildBlock), 0, st, centres_next, next_words);
-            hipLaunchKernelGGL(sah_side_kernel, dim3((unsigned)wave_chunk_blocks(nR)), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, centres, d.split, d.slot, left,
-                               centres_next);
+            const int side_places = n_act >= 64 ? 256 : kWaveChunk;
+            const size_t side_blocks = (nR + (size_t)side_places * (kBuildBlock / 64) - 1) / ((size_t)side_places * (kBuildBlock / 64));
+            hipLaunchKernelGGL(sah_side_kernel, dim3((unsigned)side_blocks), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, centres, d.split, d.slot, left,
+                               centres_next, side_places);
             bytes = temp_bytes;
             PT_HIP(ctx, rocprim::exclusive_scan(d.temp, bytes, left, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(sah_partition_kernel, grid(nR), dim3(kBuildBlock), 0, st, d.cl_lo[cur], d.cl_hi[cur], seg[cur], n, act, d.split, left, rank, d.slot, d.cl_lo[cur ^ 1],
