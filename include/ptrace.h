@@ -180,12 +180,12 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *   "tree_build"  Who builds the tree over whatever is not a copy of a shared mesh ("instancing").  0: the host's
  *                binned-SAH builder (sixteen threads: 75-95 ms for 262 k triangles, 4.3 s for ten million).  1: the device -
  *                Morton sort, the same top-down binned SAH (passes over the whole array while a node has more than 128
- *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 6 ms and 30 ms for the
+ *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 5 ms and 28 ms for the
  *                same scenes, and the same tree quality (14.96 against 14.97 node visits per ray on the first).
  *                2 (default): the device for scenes of 16 384 primitives or more, the host below.  Large triangles
  *                are cut into references ("split_percent") in a device build as in a host build.
  *                3: the device, with the two-child tree made by locally-ordered clustering from
- *                the leaves up - a third less build time on the largest scenes (21 ms for ten million), a fifth more
+ *                the leaves up - a quarter less build time on the largest scenes (21 ms for ten million), a fifth more
  *                node visits per ray.
  *                Four-child tree only; a tree too deep for a lane's traversal stack is handed to the host builder.
  *   "rebuild_percent"  30 (default): pt_update_transforms refits, which keeps the topology of the last build - after
@@ -212,7 +212,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                at the flattened tree's speed, that the host never built: 38 copies of 262 k triangles in 82 ms
  *                instead of 4.2 s, and pt_update_transforms refits it like any flattened scene (1 ms there).  When
  *                the shared meshes add up to more than a sixtieth of the scene and "tree_build" allows it, the whole
- *                scene is built flat on the device instead, which is then quicker (that scene: 36 ms).
+ *                scene is built flat on the device instead, which is then quicker (that scene: 33 ms).
  *                1: the objects - if placed by rotation or mirror x uniform scale + translation; sheared or unevenly
  *                scaled ones are flattened - share ONE tree on the device too, under a top-level tree with a box per
  *                object; triangle tests still run on world-space vertices transformed as the shader transforms them.
