@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <tuple>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -399,30 +401,83 @@ void affine_inverse_rows(const float *m, double inv[3][4])
     }
 }
 
-// An index range as a mesh: its smallest index, and a hash of the indices relative to it together with the positions they name.
-struct RangeContent { int32_t offset, count, base; uint64_t hash; };
-RangeContent range_content(int32_t offset, int32_t count, const std::vector<int32_t> &indices, const std::vector<float> &vertices)
+// fn(begin, end) over [0, n) cut into at most sixteen pieces of `grain` or more, a thread each (the caller's among them).
+template <class F> void parallel_pieces(size_t n, size_t grain, F fn)
 {
-    RangeContent rc = {offset, count, 0, 1469598103934665603ull};
-    int32_t base = std::numeric_limits<int32_t>::max();
-    for (int32_t i = offset; i < offset + count; i++) base = std::min(base, indices[(size_t)i]);
-    rc.base = count ? base : 0;
-    for (int32_t i = offset; i < offset + count; i++) {
-        uint32_t w[4];
-        w[0] = (uint32_t)(indices[(size_t)i] - rc.base);
-        std::memcpy(&w[1], &vertices[3 * (size_t)indices[(size_t)i]], 12);
-        for (uint32_t x : w) { rc.hash ^= x; rc.hash *= 1099511628211ull; rc.hash ^= rc.hash >> 29; }
-    }
-    return rc;
+    const size_t cores = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const size_t pieces = std::max<size_t>(1, std::min(cores, n / std::max<size_t>(1, grain)));
+    const size_t piece = (n + pieces - 1) / pieces;
+    std::vector<std::thread> others;
+    for (size_t t = 1; t < pieces; t++) others.emplace_back([=, &fn] { fn(std::min(n, t * piece), std::min(n, (t + 1) * piece)); });
+    fn(0, std::min(n, piece));
+    for (std::thread &t : others) t.join();
 }
-bool same_content(const RangeContent &a, const RangeContent &b, const std::vector<int32_t> &indices, const std::vector<float> &vertices)
+
+// An index range as a mesh: its smallest index, and a hash of the indices relative to the range's first index together with
+// the positions they name - a sum over the places, so that any cut of the range into pieces gives the same number.
+struct RangeContent { int32_t offset, count, base; uint64_t hash; };
+
+// Hash and smallest index of every listed range, the ranges laid end to end and shared out over the host's threads (ten
+// million triangles as 38 copies of a mesh: 150 ms on one thread).
+void range_contents(std::vector<RangeContent> &rcs, const std::vector<int32_t> &indices, const std::vector<float> &vertices)
 {
-    if (a.count != b.count || a.hash != b.hash) return false;
-    for (int32_t i = 0; i < a.count; i++) {
-        const int32_t ia = indices[(size_t)(a.offset + i)], ib = indices[(size_t)(b.offset + i)];
-        if (ia - a.base != ib - b.base || std::memcmp(&vertices[3 * (size_t)ia], &vertices[3 * (size_t)ib], 12) != 0) return false;
-    }
-    return true;
+    const size_t R = rcs.size();
+    std::vector<size_t> first(R + 1, 0);
+    for (size_t r = 0; r < R; r++) first[r + 1] = first[r] + (size_t)rcs[r].count;
+    std::vector<std::atomic<uint64_t>> hash(R);
+    std::vector<std::atomic<int32_t>> base(R);
+    for (size_t r = 0; r < R; r++) { hash[r].store(0); base[r].store(std::numeric_limits<int32_t>::max()); }
+    parallel_pieces(first[R], (size_t)1 << 16, [&](size_t b, size_t e) {
+        size_t r = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
+        while (b < e) {
+            while (first[r + 1] <= b) r++;
+            const size_t stop = std::min(e, first[r + 1]);
+            const int32_t *ix = &indices[(size_t)rcs[r].offset];
+            const int32_t head = ix[0];
+            uint64_t sum = 0; int32_t smallest = std::numeric_limits<int32_t>::max();
+            for (size_t k = b - first[r]; k < stop - first[r]; k++) {
+                uint32_t w[4];
+                w[0] = (uint32_t)(ix[k] - head);
+                std::memcpy(&w[1], &vertices[3 * (size_t)ix[k]], 12);
+                uint64_t h = (uint64_t)(k + 1) * 0x9E3779B97F4A7C15ull;
+                for (uint32_t x : w) { h = (h ^ x) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+                sum += h;
+                smallest = std::min(smallest, ix[k]);
+            }
+            hash[r].fetch_add(sum, std::memory_order_relaxed);
+            int32_t seen = base[r].load(std::memory_order_relaxed);
+            while (smallest < seen && !base[r].compare_exchange_weak(seen, smallest, std::memory_order_relaxed)) {}
+            b = stop;
+        }
+    });
+    for (size_t r = 0; r < R; r++) { rcs[r].hash = hash[r].load(); rcs[r].base = base[r].load(); }
+}
+
+// same[p]: whether the two ranges of pair p (equal lengths) hold the same mesh - the same indices relative to their smallest
+// one, naming the same positions.  All pairs end to end, shared out like the hashes.
+void same_contents(const std::vector<std::pair<RangeContent, RangeContent>> &pairs, const std::vector<int32_t> &indices, const std::vector<float> &vertices, std::vector<char> &same)
+{
+    const size_t P = pairs.size();
+    std::vector<size_t> first(P + 1, 0);
+    for (size_t p = 0; p < P; p++) first[p + 1] = first[p] + (size_t)pairs[p].first.count;
+    std::vector<std::atomic<char>> differs(P);
+    for (size_t p = 0; p < P; p++) differs[p].store(0);
+    parallel_pieces(first[P], (size_t)1 << 16, [&](size_t b, size_t e) {
+        size_t p = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
+        while (b < e) {
+            while (first[p + 1] <= b) p++;
+            const size_t stop = std::min(e, first[p + 1]);
+            const RangeContent &x = pairs[p].first, &y = pairs[p].second;
+            const int32_t *ix = &indices[(size_t)x.offset], *iy = &indices[(size_t)y.offset];
+            bool diff = false;
+            for (size_t k = b - first[p]; k < stop - first[p] && !diff; k++)
+                diff = ix[k] - x.base != iy[k] - y.base || std::memcmp(&vertices[3 * (size_t)ix[k]], &vertices[3 * (size_t)iy[k]], 12) != 0;
+            if (diff) differs[p].store(1, std::memory_order_relaxed);
+            b = stop;
+        }
+    });
+    same.resize(P);
+    for (size_t p = 0; p < P; p++) same[p] = !differs[p].load();
 }
 
 std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, const std::vector<int32_t> &indices, const std::vector<float> &vertices,
@@ -437,34 +492,62 @@ std::vector<MeshGroup> find_instances(const std::vector<PtMeshObject> &objects, 
     for (size_t o = 0; o < objects.size(); o++)
         if (objects[o].indices_count / 3 >= min_tris && objects[o].indices_offset >= 0) by_range.push_back({{objects[o].indices_offset, objects[o].indices_count}, (int)o});
     std::sort(by_range.begin(), by_range.end());
-    std::vector<RangeContent> classes;
     std::vector<std::pair<std::pair<int32_t, int32_t>, int>> keyed;      // ((offset, count) of the object's class, object)
     // a range whose length no other range has can share its content with nobody: it is not read at all when one object
-    // uses it (the usual scene of distinct meshes costs nothing here), and only for its smallest index when several do
+    // uses it (the usual scene of distinct meshes costs nothing here)
     std::vector<int32_t> lengths;
     for (size_t i = 0; i < by_range.size(); i++)
         if (i == 0 || by_range[i].first != by_range[i - 1].first) lengths.push_back(by_range[i].first.second);
     std::sort(lengths.begin(), lengths.end());
+    std::vector<RangeContent> ranges;                                    // the distinct ranges that are read
+    std::vector<std::pair<size_t, size_t>> users;                        // and the stretch of by_range that uses each
     for (size_t i = 0; i < by_range.size();) {
         size_t j = i;
         while (j < by_range.size() && by_range[j].first == by_range[i].first) j++;
-        const int32_t offset = by_range[i].first.first, count = by_range[i].first.second;
+        const int32_t count = by_range[i].first.second;
         const bool length_shared = std::upper_bound(lengths.begin(), lengths.end(), count) - std::lower_bound(lengths.begin(), lengths.end(), count) > 1;
-        if (!length_shared && j - i < 2) { i = j; continue; }
-        RangeContent rc;
-        if (length_shared) rc = range_content(offset, count, indices, vertices);
-        else {
-            rc = RangeContent{offset, count, std::numeric_limits<int32_t>::max(), 0};
-            for (int32_t k = offset; k < offset + count; k++) rc.base = std::min(rc.base, indices[(size_t)k]);
-        }
-        size_t cls = 0;
-        while (cls < classes.size() && !same_content(classes[cls], rc, indices, vertices)) cls++;
-        if (cls == classes.size()) classes.push_back(rc);
-        for (j = i; j < by_range.size() && by_range[j].first == by_range[i].first; j++) {
-            keyed.push_back({{classes[cls].offset, classes[cls].count}, by_range[j].second});
-            obj_base[(size_t)by_range[j].second] = rc.base;
-        }
+        if (length_shared || j - i >= 2) { ranges.push_back(RangeContent{by_range[i].first.first, count, 0, 0}); users.push_back({i, j}); }
         i = j;
+    }
+    range_contents(ranges, indices, vertices);
+    // ranges of one length and hash are compared with the first of them (the one that starts first); what differs after all -
+    // two meshes under one hash - goes the slow way, against every class of its length
+    std::vector<size_t> order(ranges.size());
+    for (size_t r = 0; r < order.size(); r++) order[r] = r;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        return std::make_tuple(ranges[x].count, ranges[x].hash, ranges[x].offset) < std::make_tuple(ranges[y].count, ranges[y].hash, ranges[y].offset);
+    });
+    std::vector<size_t> leader(ranges.size());
+    std::vector<std::pair<RangeContent, RangeContent>> pairs; std::vector<size_t> pair_range;
+    for (size_t k = 0; k < order.size(); k++) {
+        const size_t r = order[k];
+        const bool heads = k == 0 || ranges[order[k - 1]].count != ranges[r].count || ranges[order[k - 1]].hash != ranges[r].hash;
+        leader[r] = heads ? r : leader[order[k - 1]];
+        if (!heads) { pairs.push_back({ranges[leader[r]], ranges[r]}); pair_range.push_back(r); }
+    }
+    std::vector<char> same;
+    same_contents(pairs, indices, vertices, same);
+    std::vector<int> cls_of(ranges.size(), -1);
+    std::vector<size_t> classes;                                         // a class is named by its first range
+    for (size_t r = 0; r < ranges.size(); r++)
+        if (leader[r] == r) { cls_of[r] = (int)classes.size(); classes.push_back(r); }
+    for (size_t p = 0; p < pairs.size(); p++) {
+        const size_t r = pair_range[p];
+        if (same[p]) { cls_of[r] = cls_of[leader[r]]; continue; }
+        std::vector<char> one;
+        for (size_t c = 0; c < classes.size() && cls_of[r] < 0; c++) {
+            if (ranges[classes[c]].count != ranges[r].count) continue;
+            same_contents({{ranges[classes[c]], ranges[r]}}, indices, vertices, one);
+            if (one[0]) cls_of[r] = (int)c;
+        }
+        if (cls_of[r] < 0) { cls_of[r] = (int)classes.size(); classes.push_back(r); }
+    }
+    for (size_t r = 0; r < ranges.size(); r++) {
+        const RangeContent &rep = ranges[classes[(size_t)cls_of[r]]];
+        for (size_t j = users[r].first; j < users[r].second; j++) {
+            keyed.push_back({{rep.offset, rep.count}, by_range[j].second});
+            obj_base[(size_t)by_range[j].second] = ranges[r].base;
+        }
     }
     std::sort(keyed.begin(), keyed.end());
     for (size_t i = 0; i < keyed.size();) {
