@@ -1905,10 +1905,25 @@ int validate_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects,
             (int64_t)mo.indices_offset + mo.indices_count > n_indices)
             return fail(ctx, PT_ERR_INVALID, "mesh object " + std::to_string(o) + ": index range outside _Indices");
     }
-    for (int i = 0; i < n_indices; i++)
-        if (indices[i] < 0 || indices[i] >= n_vertices)
-            return fail(ctx, PT_ERR_INVALID, "index " + std::to_string(i) + " outside _Vertices");
+    std::atomic<int64_t> first_bad(std::numeric_limits<int64_t>::max());         // (thirty million indices take their time on one thread)
+    parallel_pieces((size_t)n_indices, (size_t)1 << 18, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++)
+            if ((uint32_t)indices[i] >= (uint32_t)n_vertices) {
+                int64_t seen = first_bad.load();
+                while ((int64_t)i < seen && !first_bad.compare_exchange_weak(seen, (int64_t)i)) {}
+                return;
+            }
+    });
+    if (first_bad.load() != std::numeric_limits<int64_t>::max())
+        return fail(ctx, PT_ERR_INVALID, "index " + std::to_string(first_bad.load()) + " outside _Vertices");
     return PT_OK;
+}
+
+// dst = src[0 .. n), the copy shared out over the host's threads when it is large.
+template <class T> void assign_parallel(std::vector<T> &dst, const T *src, size_t n)
+{
+    dst.resize(n);
+    parallel_pieces(n, ((size_t)4 << 20) / sizeof(T), [&](size_t b, size_t e) { if (e > b) std::memcpy(dst.data() + b, src + b, (e - b) * sizeof(T)); });
 }
 
 // The traversal stack's overflow area for a launch of `threads` threads with kStackOverflow entries each.
@@ -2168,8 +2183,8 @@ int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, c
     int rc = validate_meshes(ctx, objects, n_objects, n_vertices, indices, n_indices);
     if (rc) return rc;
     ctx->objects.assign(objects, objects + n_objects);
-    ctx->vertices.assign(vertices, vertices + (size_t)n_vertices * 3);
-    ctx->indices.assign(indices, indices + n_indices);
+    assign_parallel(ctx->vertices, vertices, (size_t)n_vertices * 3);
+    assign_parallel(ctx->indices, indices, (size_t)n_indices);
     ctx->mesh_cache.clear();
     ctx->scene_dirty = true;
     if (!ctx->materials.empty()) {            // materials belong to the object list they were given for
