@@ -25,7 +25,9 @@
  *   - matrices are 16 floats in UnityEngine.Matrix4x4 memory order
  *     (column-major: element (row i, col j) at [j*4+i]);
  *   - images are RGBA float32, row-major, pixel (x,y) at [(y*W + x)*4], y as
- *     SV_DispatchThreadID.y (RayTracingShader.compute:726).
+ *     SV_DispatchThreadID.y (RayTracingShader.compute:726);
+ *   - no C++ exception leaves the library: a host allocation that fails inside an entry point comes back as
+ *     PT_ERR_NOMEM with a message (pt_last_error), and the context stays usable.
  */
 #ifndef PTRACE_H
 #define PTRACE_H
@@ -38,7 +40,7 @@ extern "C" {
 
 #define PT_OK 0
 #define PT_ERR_INVALID 1   /* bad argument / bad state           */
-#define PT_ERR_HIP 2       /* a HIP runtime call failed          */
+#define PT_ERR_HIP 2       /* a HIP runtime call (or the host runtime underneath the library) failed */
 #define PT_ERR_NOMEM 3     /* host or device allocation failed   */
 #define PT_ERR_UNSUPPORTED 4
 

@@ -13,7 +13,9 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/ptrace.h"
@@ -408,7 +410,11 @@ template <class F> void parallel_pieces(size_t n, size_t grain, F fn)
     const size_t pieces = std::max<size_t>(1, std::min(cores, n / std::max<size_t>(1, grain)));
     const size_t piece = (n + pieces - 1) / pieces;
     std::vector<std::thread> others;
-    for (size_t t = 1; t < pieces; t++) others.emplace_back([=, &fn] { fn(std::min(n, t * piece), std::min(n, (t + 1) * piece)); });
+    others.reserve(pieces);
+    for (size_t t = 1; t < pieces; t++) {
+        try { others.emplace_back([=, &fn] { fn(std::min(n, t * piece), std::min(n, (t + 1) * piece)); }); }
+        catch (const std::system_error &) { fn(std::min(n, t * piece), std::min(n, (t + 1) * piece)); }      // no thread to be had: here, then
+    }
     fn(0, std::min(n, piece));
     for (std::thread &t : others) t.join();
 }
@@ -2027,6 +2033,20 @@ int finish_epoch(pt_context *ctx)
 
 }  // namespace
 
+// No C++ exception leaves the library: a host allocation that fails (or a thread that cannot be started) inside an entry point
+// becomes an error code and a message, as every other failure does.
+void note_error(pt_context *ctx, const char *msg) noexcept
+{
+    try { if (ctx) ctx->err = msg; else g_create_error = msg; } catch (...) {}
+}
+template <class F> int guarded(pt_context *ctx, F body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc &) { note_error(ctx, "out of host memory"); return PT_ERR_NOMEM; }
+    catch (const std::exception &e) { note_error(ctx, e.what()); return PT_ERR_HIP; }
+    catch (...) { note_error(ctx, "unknown exception"); return PT_ERR_HIP; }
+}
+
 extern "C" {
 
 const char *pt_version(void) { return "libptrace 0.1 (gfx950)"; }
@@ -2037,6 +2057,7 @@ unsigned long long pt_allocation_calls(void) { return g_allocation_calls.load();
 
 int pt_create(int device_ordinal, pt_context **out_ctx)
 {
+    return guarded(nullptr, [&]() -> int {
     if (!out_ctx) return fail(nullptr, PT_ERR_INVALID, "out_ctx is NULL");
     *out_ctx = nullptr;
     int count = 0;
@@ -2119,6 +2140,7 @@ int pt_create(int device_ordinal, pt_context **out_ctx)
     if (const char *env = std::getenv("PTRACE_REFILL")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(env)));
     *out_ctx = ctx;
     return PT_OK;
+    });
 }
 
 void pt_destroy(pt_context *ctx)
@@ -2157,25 +2179,30 @@ void pt_destroy(pt_context *ctx)
 
 int pt_set_stream(pt_context *ctx, void *hip_stream)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream == PT_STREAM_OWN ? ctx->own_stream : (hipStream_t)hip_stream;
     return PT_OK;
+    });
 }
 
 int pt_set_spheres(pt_context *ctx, const PtSphere *spheres, int count)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (count < 0 || (count > 0 && !spheres)) return fail(ctx, PT_ERR_INVALID, "pt_set_spheres: bad arguments");
     ctx->spheres.assign(spheres, spheres + count);
     ctx->scene_dirty = true;
     return PT_OK;
+    });
 }
 
 int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, const float *vertices,
                   int n_vertices, const int32_t *indices, int n_indices)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (n_objects < 0 || n_vertices < 0 || n_indices < 0 || (n_objects > 0 && !objects) ||
         (n_vertices > 0 && !vertices) || (n_indices > 0 && !indices))
@@ -2194,10 +2221,12 @@ int pt_set_meshes(pt_context *ctx, const PtMeshObject *objects, int n_objects, c
         free_dev(ctx->d_mesh_mat);
     }
     return PT_OK;
+    });
 }
 
 int pt_set_mesh_materials(pt_context *ctx, const PtMaterial *materials, int count)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (count < 0 || (count > 0 && !materials)) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh_materials: bad arguments");
     if (count != 0 && count != (int)ctx->objects.size())
@@ -2217,10 +2246,12 @@ int pt_set_mesh_materials(pt_context *ctx, const PtMaterial *materials, int coun
         table[(size_t)i * 3 + 2] = make_float4(m.emission[0], m.emission[1], m.emission[2], 0.0f);
     }
     return upload(ctx, ctx->d_mesh_mat, table.data(), table.size() * sizeof(float4));
+    });
 }
 
 int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_objects)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (n_objects != (int)ctx->objects.size() || (n_objects > 0 && !objects))
         return fail(ctx, PT_ERR_INVALID, "pt_update_transforms: object count differs from pt_set_meshes");
@@ -2305,10 +2336,12 @@ int pt_update_transforms(pt_context *ctx, const PtMeshObject *objects, int n_obj
         if (!(ctx->scene_lo[k] <= ctx->scene_hi[k])) ctx->scene_lo[k] = ctx->scene_hi[k] = 0.0f;
     ctx->stats.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
+    });
 }
 
 int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2320,10 +2353,12 @@ int pt_set_sky(pt_context *ctx, const float *rgba, int width, int height)
     if (rc) return rc;
     ctx->sky_w = width; ctx->sky_h = height;
     return PT_OK;
+    });
 }
 
 int pt_resize(pt_context *ctx, int width, int height)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (width <= 0 || height <= 0 || width > 32767 || height > 32767 || (int64_t)width * height > (int64_t)1 << 28)
         return fail(ctx, PT_ERR_INVALID, "pt_resize: bad size (1..32767 per side, at most 2^28 pixels)");
@@ -2363,10 +2398,12 @@ int pt_resize(pt_context *ctx, int width, int height)
     if (rebind_i || !ctx->ids) ctx->ids = ctx->own_ids;
     if (rebind_2 || !ctx->result2) ctx->result2 = ctx->own_result2;
     return PT_OK;
+    });
 }
 
 int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_bind_target before pt_resize");
     DeviceGuard g(ctx->device);
@@ -2380,6 +2417,7 @@ int pt_bind_target(pt_context *ctx, int which, void *device_ptr)
     default: return fail(ctx, PT_ERR_INVALID, "pt_bind_target: unknown target");
     }
     return PT_OK;
+    });
 }
 
 // The rectangle's 8x8 pixel blocks: blocks per row, work items, and the multiplier that stands in for the division by the
@@ -2551,6 +2589,7 @@ static int render_frame(pt_context *ctx, const PtFrameParams *p);
 
 int pt_render(pt_context *ctx, const PtFrameParams *p)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     const int rc = render_frame(ctx, p);
     if (rc != PT_OK && ctx->epoch_open) {
@@ -2559,6 +2598,7 @@ int pt_render(pt_context *ctx, const PtFrameParams *p)
         (void)hipEventRecord(ctx->ev1, ctx->stream);
     }
     return rc;
+    });
 }
 
 static int render_frame(pt_context *ctx, const PtFrameParams *p)
@@ -2725,6 +2765,7 @@ static int render_frame(pt_context *ctx, const PtFrameParams *p)
 
 int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int count)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (count < 0 || count > PT_MAX_CAMERA_HISTORY) return fail(ctx, PT_ERR_INVALID, "pt_set_camera_history: count must be 0..100");
     if (count == 0) return PT_OK;   // an empty list writes nothing into the uniform arrays
@@ -2733,10 +2774,12 @@ int pt_set_camera_history(pt_context *ctx, const PtCameraHistory *entries, int c
     else std::memcpy(ctx->camera_history.data(), entries, sizeof(PtCameraHistory) * (size_t)count);
     ctx->cams_dirty = true;
     return PT_OK;
+    });
 }
 
 int pt_set_option(pt_context *ctx, const char *name, int value)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (!name) return fail(ctx, PT_ERR_INVALID, "pt_set_option: name is NULL");
     if (std::strcmp(name, "backend") == 0) {
@@ -2782,6 +2825,11 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         ctx->instancing = value;
         return PT_OK;
     }
+    if (std::strcmp(name, "debug_throw") == 0) {          // exercises the guard around every entry point (tests): 1 bad_alloc, 2 runtime_error
+        if (value == 1) throw std::bad_alloc();
+        if (value == 2) throw std::runtime_error("debug_throw");
+        return PT_OK;
+    }
     if (std::strcmp(name, "rebuild_percent") == 0) {
         if (value < 0 || value > 10000) return fail(ctx, PT_ERR_INVALID, "pt_set_option: rebuild_percent must be 0..10000");
         ctx->rebuild_percent = value;
@@ -2805,10 +2853,12 @@ int pt_set_option(pt_context *ctx, const char *name, int value)
         return PT_OK;
     }
     return fail(ctx, PT_ERR_INVALID, std::string("pt_set_option: unknown option ") + name);
+    });
 }
 
 int pt_display_denoise(pt_context *ctx)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_display_denoise before pt_resize");
     DeviceGuard g(ctx->device);
@@ -2823,14 +2873,17 @@ int pt_display_denoise(pt_context *ctx)
     hipLaunchKernelGGL(display_denoise_kernel, grd, blk, 0, ctx->stream, (const float4 *)ctx->result, ctx->display, ctx->W, ctx->H);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
+    });
 }
 
 int pt_sync(pt_context *ctx)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
+    });
 }
 
 static int read_back(pt_context *ctx, void *dst, const void *src, size_t bytes)
@@ -2846,23 +2899,31 @@ static int read_back(pt_context *ctx, void *dst, const void *src, size_t bytes)
 
 int pt_read_result(pt_context *ctx, float *out)
 {
+    return guarded(ctx, [&]() -> int {
     return read_back(ctx, out, ctx ? ctx->result : nullptr, ctx ? (size_t)ctx->W * ctx->H * 16 : 0);
+    });
 }
 int pt_read_converged(pt_context *ctx, float *out)
 {
+    return guarded(ctx, [&]() -> int {
     return read_back(ctx, out, ctx ? ctx->conv : nullptr, ctx ? (size_t)ctx->W * ctx->H * 16 : 0);
+    });
 }
 int pt_read_hit_ids(pt_context *ctx, int32_t *out)
 {
+    return guarded(ctx, [&]() -> int {
     return read_back(ctx, out, ctx ? ctx->ids : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+    });
 }
 int pt_write_converged(pt_context *ctx, const float *in)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (!in || ctx->W == 0) return fail(ctx, PT_ERR_INVALID, "pt_write_converged: bad arguments");
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return h2d(ctx, ctx->conv, in, (size_t)ctx->W * ctx->H * 16);
+    });
 }
 
 static float4 *target_of(pt_context *ctx, int which)
@@ -2877,23 +2938,28 @@ static float4 *target_of(pt_context *ctx, int which)
 }
 int pt_read_target(pt_context *ctx, int which, float *out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     float4 *src = target_of(ctx, which);
     if (!src && ctx->W) return fail(ctx, PT_ERR_INVALID, "pt_read_target: not an RGBA target");
     return read_back(ctx, out, src, (size_t)ctx->W * ctx->H * 16);
+    });
 }
 int pt_write_target(pt_context *ctx, int which, const float *in)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     float4 *dst = target_of(ctx, which);
     if (!in || ctx->W == 0 || !dst) return fail(ctx, PT_ERR_INVALID, "pt_write_target: bad arguments");
     DeviceGuard g(ctx->device);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return h2d(ctx, dst, in, (size_t)ctx->W * ctx->H * 16);
+    });
 }
 
 int pt_get_stats(pt_context *ctx, PtStats *out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_get_stats: out is NULL");
     DeviceGuard g(ctx->device);
@@ -2901,10 +2967,12 @@ int pt_get_stats(pt_context *ctx, PtStats *out)
     if (rc) return rc;
     *out = ctx->stats;
     return PT_OK;
+    });
 }
 
 int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int brute_force, int32_t *ids_out, float *t_out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (n_rays < 0 || (n_rays > 0 && (!origins_dirs || !ids_out || !t_out)))
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays: bad arguments");
@@ -2942,10 +3010,12 @@ int pt_trace_rays(pt_context *ctx, const float *origins_dirs, int n_rays, int br
     }
     cleanup();
     return PT_OK;
+    });
 }
 
 int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays, int brute_force, int32_t *ids_out, float *t_out)
 {
+    return guarded(ctx, [&]() -> int {
     if (!ctx) return PT_ERR_INVALID;
     if (n_rays < 0 || (n_rays > 0 && (!origins_dirs || !ids_out || !t_out)))
         return fail(ctx, PT_ERR_INVALID, "pt_trace_rays_static: bad arguments");
@@ -2982,12 +3052,14 @@ int pt_trace_rays_static(pt_context *ctx, const float *origins_dirs, int n_rays,
     PT_HIP(ctx, hipMemcpyAsync(t_out, d_t, (size_t)n_rays * 4, hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
+    });
 }
 
 // ---------------------------------------------------------------- device groups
 
 int pt_group_create(int n, const int *device_ordinals, pt_group **out_group)
 {
+    return guarded(nullptr, [&]() -> int {
     if (!out_group) return fail(nullptr, PT_ERR_INVALID, "pt_group_create: out_group is NULL");
     *out_group = nullptr;
     if (n < 1 || n > 64 || !device_ordinals) return fail(nullptr, PT_ERR_INVALID, "pt_group_create: need 1..64 device ordinals");
@@ -3007,6 +3079,7 @@ int pt_group_create(int n, const int *device_ordinals, pt_group **out_group)
     }
     *out_group = g;
     return PT_OK;
+    });
 }
 
 void pt_group_destroy(pt_group *g)
@@ -3032,6 +3105,7 @@ const char *pt_group_last_error(const pt_group *g) { return g ? g->err.c_str() :
 
 int pt_group_reduce(pt_group *g, int root)
 {
+    const auto body = [&]() -> int {
     if (!g) return PT_ERR_INVALID;
     auto gfail = [&](int code, const std::string &msg) { g->err = msg; return code; };
     const int n = (int)g->members.size();
@@ -3084,6 +3158,10 @@ int pt_group_reduce(pt_group *g, int root)
     }
 #undef PT_GHIP
     return PT_OK;
+    };
+    try { return body(); }
+    catch (const std::bad_alloc &) { try { if (g) g->err = "out of host memory"; } catch (...) {} return PT_ERR_NOMEM; }
+    catch (...) { try { if (g) g->err = "exception in pt_group_reduce"; } catch (...) {} return PT_ERR_HIP; }
 }
 
 }  // extern "C"

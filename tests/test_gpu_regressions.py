@@ -466,3 +466,19 @@ def test_slivers_seen_from_far_away_keep_the_hits_that_only_rounding_produces(wi
         ib, tb = t.trace_rays(od); ie, te = t.trace_rays(od, brute_force=True)
         assert (ie == want_i).all() and (te.view(np.uint32) == want_t.view(np.uint32)).all()       # the device's exhaustive loop
         assert (ib == want_i).all() and (tb.view(np.uint32) == want_t.view(np.uint32)).all()       # and its tree
+
+
+def test_no_exception_leaves_the_library():
+    """A C++ exception inside an entry point (a host allocation that fails) comes back as an error code and a message; the
+    context stays usable.  Option "debug_throw" throws from inside pt_set_option for this test."""
+    f = pa.Scene("fixture")
+    with pa.PathTracer(0) as t:
+        lib, ctx = t._lib, t._ctx
+        assert lib.pt_set_option(ctx, b"debug_throw", 1) == pa.PT_ERR_NOMEM
+        assert b"out of host memory" in lib.pt_last_error(ctx)
+        assert lib.pt_set_option(ctx, b"debug_throw", 2) == pa.PT_ERR_HIP
+        assert b"debug_throw" in lib.pt_last_error(ctx)
+        assert lib.pt_set_option(ctx, b"debug_throw", 0) == pa.PT_OK
+        t.load_scene(f, pa.procedural_sky(16, 8)); t.resize(32, 18)
+        t.render(pa.make_params(f, 32, 18, spp=1, max_bounces=2))
+        assert np.isfinite(t.read_result()).all()
