@@ -1554,3 +1554,54 @@ def test_instances_are_recognised_in_buffers_laid_out_as_the_reference_lays_them
     assert nodes["copies", 1] < nodes["one nudged", 1] < nodes["copies", 0], nodes            # five share a tree, the nudged copy is flattened
     assert nodes["copies", 1] < nodes["one reindexed", 1] < nodes["copies", 0], nodes
     assert 5 * nodes["copies", 1] < nodes["copies", 2] < 1.5 * nodes["copies", 0], nodes       # a flat tree again, made of six copies of the shared one
+
+
+def test_shared_meshes_are_recognised_across_the_threads_of_the_search(sky_small):
+    """The search for shared meshes hashes and compares large ranges in pieces on several host threads.  Six copies of the
+    70 k-triangle mesh laid out as the reference lays them out: all six share one tree; a copy that differs in its LAST
+    vertex, or in its last triangle's winding - differences only the last piece of a range sees - stays out of the group;
+    the image is that of the flattened scene every time."""
+    b = pa.Scene("blob70k")
+    o0 = b.objects[0]
+    idx = np.array(b.indices, np.int32)[int(o0["offset"]):int(o0["offset"]) + int(o0["count"])]
+    lo, hi = int(idx.min()), int(idx.max()) + 1
+    mesh_v = np.array(b.vertices, np.float32).reshape(-1, 3)[lo:hi]; mesh_i = idx - lo
+    assert len(mesh_i) > 3 * 65536                                  # more than one piece per range
+    placements = [_trs(20 * k, (3.0 * (k % 3) - 3.0, 1.5, 4.0 * (k // 3)), 0.5 + 0.1 * k) for k in range(6)]
+
+    def layout(nudged=None, reindexed=None):
+        verts, index, objs = [], [], np.zeros(len(placements), b.objects.dtype)
+        n_v = n_i = 0
+        for k, m in enumerate(placements):
+            v = mesh_v.copy(); i = mesh_i.copy()
+            if k == nudged:
+                v[int(i[-1]), 1] += 0.25
+            if k == reindexed:
+                i[-3:] = i[[-3, -1, -2]]
+            verts.append(v); index.append(i + n_v)
+            objs[k] = (m, n_i, len(i))
+            n_v += len(v); n_i += len(i)
+        return objs, np.concatenate(verts), np.concatenate(index).astype(np.int32)
+
+    W, H = 160, 90
+    p = pa.make_params(b, W, H, spp=1, max_bounces=3, seed=0.31, eye=(0.0, 4.0, -9.0), target=(0.0, 1.5, 2.0), fov=60)
+    nodes = {}
+    with pa.PathTracer(0) as t:
+        t.set_sky(sky_small); t.resize(W, H); t.set_spheres(b.spheres)
+        t.set_option("tree_build", 0)                               # the host builder: instancing decides what it builds
+        for label, kw in (("copies", {}), ("last vertex nudged", dict(nudged=4)), ("last triangle turned", dict(reindexed=2))):
+            objs, verts, index = layout(**kw)
+            images = {}
+            for inst in (0, 1, 2):
+                t.set_option("instancing", inst)
+                t.set_meshes(objs, verts, index)
+                t.stats(); t.render(p)
+                nodes[label, inst] = t.stats()["bvh_nodes"]
+                images[inst] = (t.read_result(), t.read_hit_ids())
+            for inst in (1, 2):
+                assert (images[inst][1] == images[0][1]).all(), (label, inst)
+                _assert_same_image(images[inst][0], images[0][0], f"{label}, instancing {inst}")
+            assert (images[0][1] > len(b.spheres)).mean() > 0.05
+    assert nodes["copies", 1] < 0.25 * nodes["copies", 0], nodes                           # six copies, one tree
+    for label in ("last vertex nudged", "last triangle turned"):                          # five share a tree, the sixth is flattened
+        assert 1.5 * nodes["copies", 1] < nodes[label, 1] < 0.5 * nodes["copies", 0], (label, nodes)
