@@ -184,7 +184,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                Morton sort, the same top-down binned SAH (passes over the whole array while a node has more than 128
  *                primitives, then one wave per node in LDS), collapse, boxes by the refit kernels: 5 ms and 28 ms for the
  *                same scenes, and the same tree quality (14.96 against 14.97 node visits per ray on the first).
- *                2 (default): the device for scenes of 16 384 primitives or more, the host below.  Large triangles
+ *                2 (default): the device for scenes of 3 072 primitives or more, the host below.  Large triangles
  *                are cut into references ("split_percent") in a device build as in a host build.
  *                3: the device, with the two-child tree made by locally-ordered clustering from
  *                the leaves up - a quarter less build time on the largest scenes (21 ms for ten million), a fifth more
