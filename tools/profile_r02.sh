@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round-2 profile files are made from, in one call on the GPU box (outputs under gpurun_out/r02/).
+# Everything the profiles/r02_* files are made from, in one call on the GPU box (outputs under gpurun_out/r02/).
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 O=gpurun_out/r02; mkdir -p $O

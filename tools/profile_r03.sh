@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round-3 profile files are made from, in one call on the GPU box (outputs under gpurun_out/r03p/).
+# Everything the profiles/r03_* files are made from, in one call on the GPU box (outputs under gpurun_out/r03p/).
 # Needs the measurement builds csrc/libptrace_prof.so (-DPT_PROFILE_PHASES), csrc/libptrace_w4.so (-DPT_SCHED_WAVES=4) and
 # csrc/libptrace_3load.so (-DPT_NODES_3LOAD): tools/build_measurement_libs.sh.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
