@@ -35,8 +35,13 @@ using namespace ptrace;
 // memory before and after would not show a hipMalloc that was followed by its hipFree.
 namespace {
 std::atomic<unsigned long long> g_allocation_calls{0};
-inline hipError_t dev_malloc(void **p, size_t bytes) { g_allocation_calls++; return hipMalloc(p, bytes); }
-inline hipError_t dev_free(void *p) { g_allocation_calls++; return hipFree(p); }
+std::atomic<unsigned long long> g_allocation_ns{0};          // time inside hipMalloc / hipFree (reported by PTRACE_BUILD_TIMING)
+struct AllocationClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocationClock() { g_allocation_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+inline hipError_t dev_malloc(void **p, size_t bytes) { g_allocation_calls++; AllocationClock c; return hipMalloc(p, bytes); }
+inline hipError_t dev_free(void *p) { g_allocation_calls++; AllocationClock c; return hipFree(p); }
 inline hipError_t host_malloc(void **p, size_t bytes, unsigned flags) { g_allocation_calls++; return hipHostMalloc(p, bytes, flags); }
 inline hipError_t host_free(void *p) { g_allocation_calls++; return hipHostFree(p); }
 }  // namespace
@@ -641,6 +646,7 @@ struct DeviceArena {
 int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_first_tri, size_t nt, std::chrono::steady_clock::time_point t_called)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    const unsigned long long alloc_ns0 = g_allocation_ns.load(), alloc_calls0 = g_allocation_calls.load();
     const int nS = (int)ctx->spheres.size();
     const size_t nO = ctx->objects.size();
     const size_t nP = (size_t)nS + nt;
@@ -1119,8 +1125,9 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
     if (std::getenv("PTRACE_BUILD_TIMING")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
         std::fprintf(stderr, "scene build on the device: %d primitives, %d references, %d nodes in %d levels, stack need %d, %d clustering rounds, %.0f MB of scratch; before the build %.1f ms, upload + bounds %.1f ms, "
-                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms\n", (int)nP, n, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
-                     ms(t_called, t0), ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()));
+                             "records + sort %.1f ms, two-child tree %.1f ms, collapse %.1f ms, gather + boxes %.1f ms; %.2f ms of it in %llu hipMalloc / hipFree calls\n", (int)nP, n, n4, levels, stack_need, rounds, arena_bytes / 1048576.0,
+                     ms(t_called, t0), ms(t0, t_bounds), ms(t_bounds, t_sorted), ms(t_sorted, t_tree), ms(t_tree, t_wide), ms(t_wide, std::chrono::steady_clock::now()),
+                     (g_allocation_ns.load() - alloc_ns0) * 1e-6, g_allocation_calls.load() - alloc_calls0);
     }
     ctx->scene_dirty = false;
     ctx->bvh2_stale = false;
