@@ -144,6 +144,10 @@ struct pt_context {
     size_t cost_blocks = 0;
     hipEvent_t ev_cost = nullptr;
     bool cost_pending = false;        // h_cost is being written by the copy ev_cost follows
+    // the device builder's two scratch areas, kept between builds while they are small (a scene that changes every frame
+    // would otherwise pay four hipMalloc / hipFree calls of a hundred megabytes per build)
+    char *build_scratch[2] = {nullptr, nullptr};
+    size_t build_scratch_bytes[2] = {0, 0};
     float4 *d_inst = nullptr;         // SceneDev::inst
     std::vector<CachedMesh> mesh_cache;
     uint64_t mesh_versions = 0;
@@ -627,6 +631,7 @@ int refit_expanded(pt_context *ctx, const RefitArgs &ra)
 constexpr size_t kDeviceBuildMinPrims = 3072;        // option tree_build 2: scenes below this build on the host (2 000 triangles: 1.7 ms against 1.8; 4 000: 3.4 against 2.0)
 constexpr int kDeviceBuildFallback = -1000;          // not an error: the caller goes on with the host build
 constexpr int kDeviceBuildMaxLevels = 2048;
+constexpr size_t kDeviceBuildKeepBytes = (size_t)256 << 20;       // scratch areas up to this size stay with the context between builds
 constexpr int kDeviceBuildTopClusters = 8192;        // clusters at which the clustering rounds stop and the host builds the top of the tree
 
 // One device allocation cut into 256-byte-aligned parts: first a dry run for the size, then the same calls for the pointers.
@@ -696,11 +701,29 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         a.take(d.indices, ctx->indices.size()); a.take(d.objects, nO + 1); a.take(d.bounds, n_bounds); a.take(d.large, nP + 1);
         a.take(d.src, nP); a.take(d.prims, nP * 3); a.take(d.box, nP * 6);
     };
-    struct Release { char *p = nullptr; ~Release() { if (p) (void)dev_free(p); } } first_arena, second_arena;
+    // scratch area `which` of at least `bytes`: the context's if it is large enough, else a new one in its place; areas
+    // beyond kDeviceBuildKeepBytes go when this function returns
+    struct Scratch {
+        pt_context *ctx; int which; char *p = nullptr;
+        ~Scratch()
+        {
+            if (ctx->build_scratch_bytes[which] > kDeviceBuildKeepBytes) { free_dev(ctx->build_scratch[which]); ctx->build_scratch_bytes[which] = 0; }
+        }
+    } first_arena{ctx, 0}, second_arena{ctx, 1};
+    const auto scratch = [&](Scratch &a, size_t bytes) -> hipError_t {
+        if (ctx->build_scratch_bytes[a.which] < bytes) {
+            free_dev(ctx->build_scratch[a.which]); ctx->build_scratch_bytes[a.which] = 0;
+            const hipError_t e = dev_malloc((void **)&ctx->build_scratch[a.which], bytes);
+            if (e != hipSuccess) { ctx->build_scratch[a.which] = nullptr; return e; }
+            ctx->build_scratch_bytes[a.which] = bytes;
+        }
+        a.p = ctx->build_scratch[a.which];
+        return hipSuccess;
+    };
     DeviceArena arena;
     layout_first(arena);
     size_t arena_bytes = arena.used;
-    PT_HIP(ctx, dev_malloc((void **)&first_arena.p, arena_bytes));
+    PT_HIP(ctx, scratch(first_arena, arena_bytes));
     arena = DeviceArena(); arena.base = first_arena.p;
     layout_first(arena);
     const auto grid = [](size_t count) { return dim3((unsigned)((count + kBuildBlock - 1) / kBuildBlock)); };
@@ -836,7 +859,7 @@ int build_scene_on_device(pt_context *ctx, const std::vector<uint32_t> &obj_firs
         arena = DeviceArena();
         layout_second(arena);
         arena_bytes += arena.used;
-        PT_HIP(ctx, dev_malloc((void **)&second_arena.p, arena.used));
+        PT_HIP(ctx, scratch(second_arena, arena.used));
         d = first;
         arena = DeviceArena(); arena.base = second_arena.p;
         layout_second(arena);
@@ -1179,6 +1202,7 @@ int rebuild_scene(pt_context *ctx)
     }
 #endif
     ctx->device_built = false;
+    for (int k = 0; k < 2; k++) { free_dev(ctx->build_scratch[k]); ctx->build_scratch_bytes[k] = 0; }      // the host builds this scene: nothing to keep scratch for
     std::vector<Aabb> group_bounds(groups.size()); std::vector<char> group_bounds_done(groups.size(), 0);
     {
         size_t n_flat = 0;
@@ -2173,6 +2197,7 @@ void pt_destroy(pt_context *ctx)
         if (ctx->ev_cams[i]) (void)hipEventDestroy(ctx->ev_cams[i]);
     }
     if (ctx->ev_refit) (void)hipEventDestroy(ctx->ev_refit);
+    free_dev(ctx->build_scratch[0]); free_dev(ctx->build_scratch[1]);
     if (ctx->ev_cost) (void)hipEventDestroy(ctx->ev_cost);
     free_dev(ctx->d_cost);
     if (ctx->h_cost) (void)host_free(ctx->h_cost);
