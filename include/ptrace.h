@@ -195,6 +195,8 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                device-built tree is taken on the device after every refit and read by a later pt_render without
  *                waiting for it; when it exceeds the freshly built tree's by this many per cent, that render builds
  *                anew (on the device: milliseconds).  0: never.  Trees built by the host are only ever refitted.
+ *   "debug_throw"  a test hook: 1 throws std::bad_alloc, 2 std::runtime_error from inside the call, which must come back
+ *                as PT_ERR_NOMEM / PT_ERR_HIP like any exception under an entry point; 0 does nothing.
  *   "blocks_per_cu"  0 (default): the persistent kernel takes every resident-block slot of the GPU; n > 0: at most
  *                n blocks per compute unit, which leaves room for another context's dispatch to run alongside
  *                (two eyes of a stereo pair on one GPU: 2 each).
