@@ -215,7 +215,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream);
  *                What the kernels walk is an ordinary flattened world-space tree (any backend, any localToWorld),
  *                at the flattened tree's speed, that the host never built: 38 copies of 262 k triangles in 82 ms
  *                instead of 4.2 s, and pt_update_transforms refits it like any flattened scene (1 ms there).  When
- *                the shared meshes add up to more than a sixtieth of the scene and "tree_build" allows it, the whole
+ *                the shared meshes add up to more than a hundredth of the scene and "tree_build" allows it, the whole
  *                scene is built flat on the device instead, which is then quicker (that scene: 33 ms).
  *                1: the objects - if placed by rotation or mirror x uniform scale + translation; sheared or unevenly
  *                scaled ones are flattened - share ONE tree on the device too, under a top-level tree with a box per

@@ -1187,13 +1187,13 @@ int rebuild_scene(pt_context *ctx)
     ctx->flatten_once = false;
 #if !defined(PT_NODES_SOA) && !defined(PT_NODES_3LOAD)
     // Copies of shared meshes (instancing 2) spare the host the big tree, not the small one: the mesh's own tree is still the
-    // host builder's, 70 ms for 262 k triangles.  The device builds ALL ten million of that scene's triangles in 50 ms, so
-    // copying only pays when the meshes are small against the scene: by the two builders' rates, a sixtieth of it or less.
+    // host builder's, 70 ms for 262 k triangles.  The device builds ALL ten million of that scene's triangles in 28 ms, so
+    // copying only pays when the meshes are small against the scene: by the two builders' rates, a hundredth of it or less.
     bool flat_is_quicker = groups.empty();
     if (!groups.empty() && expand) {
         size_t mesh_tris = 0;
         for (const MeshGroup &g : groups) mesh_tris += (size_t)g.indices_count / 3;
-        flat_is_quicker = 60 * mesh_tris > nt;
+        flat_is_quicker = 100 * mesh_tris > nt;
     }
     if (flat_is_quicker && ctx->bvh_width == 4 &&
         (ctx->tree_build == 1 || ctx->tree_build == 3 || (ctx->tree_build == 2 && (size_t)nS + nt >= kDeviceBuildMinPrims))) {
