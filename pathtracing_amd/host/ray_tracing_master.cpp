@@ -304,15 +304,25 @@ using namespace ptm;
 struct ptm_scene { Scene *s; };
 struct ptm_master { RayTracingMaster *m; std::string create_error; };
 
+// No C++ exception leaves this library either: what throws under an entry point (a host allocation that fails) comes back as a code.
+template <class F> static int ptm_guarded(F body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc &) { return PT_ERR_NOMEM; }
+    catch (...) { return PT_ERR_HIP; }
+}
+
 extern "C" {
 
 int ptm_sphere_field(int seed, uint32_t spheres_max, float rmin, float rmax, float placement_radius, PtSphere *out, int capacity)
 {
+    return ptm_guarded([&]() -> int {
     std::vector<PtSphere> v;
     int n = sphere_field(seed, spheres_max, rmin, rmax, placement_radius, v);
     if (n > capacity) n = capacity;
     if (out && n > 0) std::memcpy(out, v.data(), sizeof(PtSphere) * (size_t)n);
     return n;
+    });
 }
 
 void ptm_sky_procedural(int w, int h, float *rgba) { sky_procedural(w, h, rgba); }
@@ -321,6 +331,7 @@ static thread_local std::string g_sky_error;
 const char *ptm_sky_error(void) { return g_sky_error.c_str(); }
 int ptm_sky_load_hdr(const char *path, int max_size, int *w, int *h, float *rgba, int capacity_texels)
 {
+    return ptm_guarded([&]() -> int {
     g_sky_error.clear();
     if (!path || !w || !h) { g_sky_error = "ptm_sky_load_hdr: NULL argument"; return -1; }
     std::vector<float> img; int iw = 0, ih = 0;
@@ -331,6 +342,7 @@ int ptm_sky_load_hdr(const char *path, int max_size, int *w, int *h, float *rgba
         std::memcpy(rgba, img.data(), img.size() * sizeof(float));
     }
     return 0;
+    });
 }
 
 void ptm_camera_look_at(const float eye[3], const float target[3], const float up[3], float fov, float aspect,
@@ -357,9 +369,11 @@ void ptm_camera_stereo_eye(const float eye[3], const float target[3], const floa
 
 ptm_scene *ptm_scene_create(const char *name)
 {
-    Scene *s = Scene::create(name ? name : "");
-    if (!s) return nullptr;
-    return new ptm_scene{s};
+    try {
+        Scene *s = Scene::create(name ? name : "");
+        if (!s) return nullptr;
+        return new ptm_scene{s};
+    } catch (...) { return nullptr; }
 }
 void ptm_scene_destroy(ptm_scene *s) { if (s) { delete s->s; delete s; } }
 void ptm_scene_counts(const ptm_scene *s, int32_t c[4])
@@ -379,29 +393,35 @@ void ptm_scene_camera(const ptm_scene *s, float eye[3], float target[3], float *
 {
     std::memcpy(eye, s->s->eye, 12); std::memcpy(target, s->s->target, 12); *fov = s->s->fov;
 }
-int ptm_scene_add_obj(ptm_scene *s, const char *path, const float m[16]) { return s->s->add_obj(path, m); }
+int ptm_scene_add_obj(ptm_scene *s, const char *path, const float m[16]) { return ptm_guarded([&]() -> int { return s->s->add_obj(path, m); }); }
 
 int ptm_master_create(int device, ptm_master **out)
 {
+    return ptm_guarded([&]() -> int {
     if (!out) return PT_ERR_INVALID;
     ptm_master *h = new ptm_master{new RayTracingMaster(device), ""};
     *out = h;
     if (!h->m->ok()) return PT_ERR_HIP;   // handle stays valid so the caller can read the error, then destroy it
     return PT_OK;
+    });
 }
 void ptm_master_destroy(ptm_master *m) { if (m) { delete m->m; delete m; } }
 const char *ptm_master_error(const ptm_master *m) { return m ? m->m->error().c_str() : "null master"; }
 pt_context *ptm_master_context(ptm_master *m) { return m->m->context(); }
 int ptm_master_set_sky_hdr(ptm_master *m, const char *path, int max_size)
 {
+    return ptm_guarded([&]() -> int {
     if (!m || !path) return PT_ERR_INVALID;
     return m->m->SetSkyboxTexture(path, max_size);
+    });
 }
 
 int ptm_master_load_scene(ptm_master *m, const ptm_scene *s, int sky_w, int sky_h)
 {
+    return ptm_guarded([&]() -> int {
     std::memcpy(m->m->eye, s->s->eye, 12); std::memcpy(m->m->target, s->s->target, 12); m->m->fieldOfView = s->s->fov;
     return m->m->OnEnable(*s->s, sky_w, sky_h);
+    });
 }
 int ptm_master_configure(ptm_master *m, int width, int height, int spp, int max_bounces, int depth, int accumulate, uint32_t sample_frames)
 {
@@ -438,13 +458,15 @@ int ptm_master_set_stereo(ptm_master *m, int enabled, int left_eye, const float 
 }
 int ptm_master_register_object(ptm_master *m, const float *vertices, int n_vertices, const int32_t *indices, int n_indices, const float local_to_world[16])
 {
+    return ptm_guarded([&]() -> int {
     return m->m->RegisterObject(vertices, n_vertices, indices, n_indices, local_to_world);
+    });
 }
-int ptm_master_register_instance(ptm_master *m, int of_object, const float local_to_world[16]) { return m->m->RegisterInstance(of_object, local_to_world); }
-int ptm_master_unregister_object(ptm_master *m, int object) { return m->m->UnregisterObject(object); }
-int ptm_master_update_object(ptm_master *m, int object, const float local_to_world[16]) { return m->m->UpdateObject(object, local_to_world); }
+int ptm_master_register_instance(ptm_master *m, int of_object, const float local_to_world[16]) { return ptm_guarded([&]() -> int { return m->m->RegisterInstance(of_object, local_to_world); }); }
+int ptm_master_unregister_object(ptm_master *m, int object) { return ptm_guarded([&]() -> int { return m->m->UnregisterObject(object); }); }
+int ptm_master_update_object(ptm_master *m, int object, const float local_to_world[16]) { return ptm_guarded([&]() -> int { return m->m->UpdateObject(object, local_to_world); }); }
 int ptm_master_object_count(const ptm_master *m) { return m->m->objectCount(); }
-int ptm_master_render(ptm_master *m) { return m->m->Render(); }
+int ptm_master_render(ptm_master *m) { return ptm_guarded([&]() -> int { return m->m->Render(); }); }
 int ptm_master_peek_params(ptm_master *m, PtFrameParams *out) { m->m->FillParams(*out); return PT_OK; }
 void ptm_master_reset_accumulation(ptm_master *m) { m->m->ResetAccumulation(); }
 uint32_t ptm_master_current_sample(const ptm_master *m) { return m->m->currentSample(); }
