@@ -498,6 +498,7 @@ def main():
             # the headline workload with the eye advancing 0.02 units per step: every dispatch hands its blocks out by the
             # costs the PREVIOUS camera position measured
             out["value_moving_camera"] = moving_camera_rate(pa, tr, scene, args)
+            out["scene_change"] = scene_change_time(pa, torch, scene, sky)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, args)
             out["cpu_baseline_c1"] = cpu_baseline_c1(args)
@@ -667,6 +668,31 @@ def c1_gpu(pa, torch, frames=20):
     t.close()
     return {"value": st["rays"] / frames / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt * 1e3, "frames": frames,
             "config": f"spheres scene ({len(scene.spheres)} spheres + ground plane + sky), {W}x{H}, 8 bounces, 1 spp, 1 GPU, one dispatch at a time"}
+
+
+def scene_change_time(pa, torch, scene, sky, repeats=4):
+    """What a scene change costs on the headline scene, from pt_set_meshes to the first finished frame: the call itself
+    (checks and copies the buffers), then a small 1-spp frame that has to wait for the tree (built on the device by
+    default).  The reference's counterpart is the buffer re-upload of RebuildMeshObjectBuffers (RayTracingMaster.cs:371-413)."""
+    W, H = 320, 180
+    t = pa.PathTracer(torch.cuda.current_device())
+    t.load_scene(scene, sky); t.resize(W, H)
+    p = pa.make_params(scene, W, H, seed=0.5, spp=1, max_bounces=4)
+    t.render(p); t.sync()
+    best = None
+    for k in range(repeats):
+        t.sync(); t0 = time.perf_counter()
+        t.set_meshes(scene.objects, scene.vertices, scene.indices)
+        t1 = time.perf_counter()
+        t.render(p); t.sync()
+        t2 = time.perf_counter()
+        st = t.stats()
+        cur = {"set_meshes_ms": (t1 - t0) * 1e3, "first_frame_ms": (t2 - t1) * 1e3, "build_ms": st["bvh_build_ms"], "frame_kernel_ms": st["kernel_ms"]}
+        if best is None or cur["set_meshes_ms"] + cur["first_frame_ms"] < best["set_meshes_ms"] + best["first_frame_ms"]:
+            best = cur
+    t.close()
+    best["config"] = f"{scene.name}: pt_set_meshes with the same {scene.n_triangles} triangles, then a {W}x{H} frame of 1 spp; best of {repeats}"
+    return best
 
 
 def moving_camera_rate(pa, tr, scene, args, steps=6):
